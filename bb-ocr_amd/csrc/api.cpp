@@ -1,0 +1,1165 @@
+// C-ABI of libbbocr (include/bbocr.h): context, weight folding/packing, detector / box / recogniser pipelines.
+// Host orchestration only; every arithmetic stage is a HIP kernel (conv_mfma.hip, craft_misc.hip, ccl.hip,
+// crnn_misc.hip, lstm.hip, ctc.hip) or the O(#boxes) geometry in boxpost.cpp.
+#include "../../include/bbocr.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "boxpost.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct StatusError {
+    int code;
+    std::string msg;
+};
+[[noreturn]] static void fail(int code, const std::string& m) { throw StatusError{code, m}; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) fail(BBOCR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc(&p, n));
+        cap = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Arena {   // bump allocator over one device buffer; a dry pass sizes it, the real pass carves it
+    DevBuf buf;
+    size_t off = 0;
+    bool dry = true;
+    void begin(bool d) { off = 0; dry = d; }
+    template <typename T> T* alloc(size_t count) {
+        off = align_up(off, 256);
+        T* r = dry ? nullptr : (T*)((char*)buf.p + off);
+        off += count * sizeof(T);
+        return r;
+    }
+};
+
+struct Act {   // bf16 NHWC activation
+    uint16_t* p;
+    int N, H, W, C;
+};
+
+}  // namespace
+
+struct bbocr_ctx {
+    bbocr_config cfg{};
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    float times[8] = {0};
+
+    // ---- detector
+    bool craft_loaded = false;
+    uint16_t* c11_w = nullptr;
+    float* c11_b = nullptr;
+    ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
+    ConvPlan up1a, up1b, up2a, up2b, up3a, up3b, up4a, up4b, cls0, cls2, cls4;
+    float* cls_tail = nullptr;   // w1[256] b1[16] w2[32] b2[2]
+    // ---- recogniser
+    bool crnn_loaded = false;
+    float* r0_wb = nullptr;      // w[32*9] b[32]
+    ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
+    uint16_t* whh[2] = {nullptr, nullptr};
+    std::vector<void*> owned;    // every hipMalloc'd weight block
+
+    Arena arena;
+    DevBuf heat, gray, resized;
+    DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
+    DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
+    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ weights
+struct TensorMap {
+    std::unordered_map<std::string, const bbocr_tensor_desc*> m;
+    TensorMap(const bbocr_tensor_desc* d, int n) {
+        for (int i = 0; i < n; ++i) {
+            std::string k = d[i].name ? d[i].name : "";
+            if (k.rfind("module.", 0) == 0) k = k.substr(7);
+            m[k] = &d[i];
+        }
+    }
+    const float* get(const std::string& name, size_t numel, bool required = true) const {
+        auto it = m.find(name);
+        if (it == m.end()) {
+            if (required) fail(BBOCR_ERR_WEIGHTS, "missing tensor '" + name + "'");
+            return nullptr;
+        }
+        size_t n = 1;
+        for (int i = 0; i < it->second->ndim; ++i) n *= (size_t)it->second->shape[i];
+        if (n != numel || !it->second->data)
+            fail(BBOCR_ERR_WEIGHTS, "tensor '" + name + "' has " + std::to_string(n) + " elements, expected " + std::to_string(numel));
+        return it->second->data;
+    }
+};
+
+// conv (+ optional BatchNorm in eval mode) -> folded fp32 weight [Cout][Cin][K] and bias [Cout]
+static void fold_conv(const TensorMap& tm, const std::string& conv, const std::string& bn, int Cout, int Cin, int K, std::vector<float>& w,
+                      std::vector<float>& b) {
+    const size_t per = (size_t)Cin * K;
+    const float* cw = tm.get(conv + ".weight", (size_t)Cout * per);
+    const float* cb = tm.get(conv + ".bias", (size_t)Cout, false);
+    w.assign(cw, cw + (size_t)Cout * per);
+    b.assign(Cout, 0.f);
+    if (cb) std::copy(cb, cb + Cout, b.begin());
+    if (!bn.empty()) {
+        const float* g = tm.get(bn + ".weight", Cout);
+        const float* be = tm.get(bn + ".bias", Cout);
+        const float* mu = tm.get(bn + ".running_mean", Cout);
+        const float* var = tm.get(bn + ".running_var", Cout);
+        for (int o = 0; o < Cout; ++o) {
+            const float sc = g[o] / std::sqrt(var[o] + 1e-5f);
+            for (size_t i = 0; i < per; ++i) w[(size_t)o * per + i] *= sc;
+            b[o] = (b[o] - mu[o]) * sc + be[o];
+        }
+    }
+}
+
+static ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil) {
+    ConvPlan p;
+    p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad_h = pad; p.pad_w = pad; p.dil = dil;
+    p.Cin_pad = cdiv(Cin, 32) * 32;
+    if (Cout >= 256) { p.BN = 256; p.Cout_pad = cdiv(Cout, 256) * 256; }
+    else if (Cout > 64) { p.BN = 128; p.Cout_pad = 128; }
+    else { p.BN = 64; p.Cout_pad = 64; }
+    return p;
+}
+
+template <typename T> static T* upload(bbocr_ctx* c, const std::vector<T>& v) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, v.size() * sizeof(T)));
+    c->owned.push_back(d);
+    HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return (T*)d;
+}
+
+static void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b) {
+    std::vector<uint16_t> pk(conv_packed_elems(p));
+    pack_conv_weights(p, w.data(), pk.data());
+    std::vector<float> bp(p.Cout_pad, 0.f);
+    std::copy(b.begin(), b.end(), bp.begin());
+    p.d_w = upload(c, pk);
+    p.d_b = upload(c, bp);
+}
+
+static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std::string& conv, const std::string& bn, int Cin, int Cout,
+                       int K, int pad, int dil) {
+    p = make_plan(Cin, Cout, K, K, pad, dil);
+    std::vector<float> w, b;
+    fold_conv(tm, conv, bn, Cout, Cin, K * K, w, b);
+    upload_plan(c, p, w, b);
+}
+
+static void free_weights(bbocr_ctx* c) {
+    for (void* p : c->owned) (void)hipFree(p);
+    c->owned.clear();
+    c->craft_loaded = c->crnn_loaded = false;
+}
+
+static void load_craft(bbocr_ctx* c, const TensorMap& tm) {
+    {
+        std::vector<float> w, b;
+        fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);
+        std::vector<uint16_t> pk(2 * 4 * 64 * 8);
+        pack_conv1_1_weights(w.data(), pk.data());
+        c->c11_w = upload(c, pk);
+        c->c11_b = upload(c, b);
+    }
+    load_layer(c, tm, c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1);
+    load_layer(c, tm, c->conv2_1, "basenet.slice1.7", "basenet.slice1.8", 64, 128, 3, 1, 1);
+    load_layer(c, tm, c->conv2_2, "basenet.slice1.10", "basenet.slice1.11", 128, 128, 3, 1, 1);
+    load_layer(c, tm, c->conv3_1, "basenet.slice2.14", "basenet.slice2.15", 128, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv3_2, "basenet.slice2.17", "basenet.slice2.18", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv3_3, "basenet.slice3.20", "basenet.slice3.21", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv4_1, "basenet.slice3.24", "basenet.slice3.25", 256, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv4_2, "basenet.slice3.27", "basenet.slice3.28", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv4_3, "basenet.slice4.30", "basenet.slice4.31", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6);
+    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1);
+    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1);
+    load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1);
+    load_layer(c, tm, c->up2a, "upconv2.conv.0", "upconv2.conv.1", 768, 256, 1, 0, 1);
+    load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1);
+    load_layer(c, tm, c->up3a, "upconv3.conv.0", "upconv3.conv.1", 384, 128, 1, 0, 1);
+    load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1);
+    load_layer(c, tm, c->up4a, "upconv4.conv.0", "upconv4.conv.1", 192, 64, 1, 0, 1);
+    load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1);
+    {
+        std::vector<float> t(256 + 16 + 32 + 2);
+        const float* w1 = tm.get("conv_cls.6.weight", 256);
+        const float* b1 = tm.get("conv_cls.6.bias", 16);
+        const float* w2 = tm.get("conv_cls.8.weight", 32);
+        const float* b2 = tm.get("conv_cls.8.bias", 2);
+        std::copy(w1, w1 + 256, t.begin());
+        std::copy(b1, b1 + 16, t.begin() + 256);
+        std::copy(w2, w2 + 32, t.begin() + 272);
+        std::copy(b2, b2 + 2, t.begin() + 304);
+        c->cls_tail = upload(c, t);
+    }
+    c->craft_loaded = true;
+}
+
+static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
+    const std::string fe = "FeatureExtraction.ConvNet.";
+    {
+        std::vector<float> t(32 * 9 + 32);
+        const float* w = tm.get(fe + "0.weight", 32 * 9);
+        const float* b = tm.get(fe + "0.bias", 32);
+        std::copy(w, w + 288, t.begin());
+        std::copy(b, b + 32, t.begin() + 288);
+        c->r0_wb = upload(c, t);
+    }
+    load_layer(c, tm, c->r1, fe + "3", "", 32, 64, 3, 1, 1);
+    load_layer(c, tm, c->r2, fe + "6", "", 64, 128, 3, 1, 1);
+    load_layer(c, tm, c->r3, fe + "8", "", 128, 128, 3, 1, 1);
+    load_layer(c, tm, c->r4, fe + "11", fe + "12", 128, 256, 3, 1, 1);
+    load_layer(c, tm, c->r5, fe + "14", fe + "15", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->r6, fe + "18", "", 256, 256, 2, 0, 1);
+    for (int l = 0; l < 2; ++l) {
+        const std::string sm = "SequenceModeling." + std::to_string(l) + ".";
+        // input projection of both directions as one 1x1 conv with the channel permutation the LSTM kernel reads
+        std::vector<float> w((size_t)2048 * 256), b(2048);
+        for (int d = 0; d < 2; ++d) {
+            const std::string sfx = d ? "_reverse" : "";
+            const float* wih = tm.get(sm + "rnn.weight_ih_l0" + sfx, (size_t)1024 * 256);
+            const float* bih = tm.get(sm + "rnn.bias_ih_l0" + sfx, 1024);
+            const float* bhh = tm.get(sm + "rnn.bias_hh_l0" + sfx, 1024);
+            for (int g = 0; g < 4; ++g)
+                for (int u = 0; u < 256; ++u) {
+                    const int src = g * 256 + u, dst = lstm_xproj_channel(d, g, u);
+                    std::copy(wih + (size_t)src * 256, wih + (size_t)src * 256 + 256, w.begin() + (size_t)dst * 256);
+                    b[dst] = bih[src] + bhh[src];
+                }
+        }
+        c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1);
+        upload_plan(c, c->xproj[l], w, b);
+        const float* hf = tm.get(sm + "rnn.weight_hh_l0", (size_t)1024 * 256);
+        const float* hb = tm.get(sm + "rnn.weight_hh_l0_reverse", (size_t)1024 * 256);
+        std::vector<uint16_t> pk(lstm_whh_packed_elems());
+        pack_lstm_whh(hf, hb, pk.data());
+        c->whh[l] = upload(c, pk);
+        std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
+        std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);
+        c->lin[l] = make_plan(512, 256, 1, 1, 0, 1);
+        upload_plan(c, c->lin[l], lw, lb);
+    }
+    {
+        std::vector<float> pw(tm.get("Prediction.weight", (size_t)97 * 256), tm.get("Prediction.weight", (size_t)97 * 256) + 97 * 256);
+        std::vector<float> pb(tm.get("Prediction.bias", 97), tm.get("Prediction.bias", 97) + 97);
+        c->pred = make_plan(256, 97, 1, 1, 0, 1);
+        upload_plan(c, c->pred, pw, pb);
+    }
+    c->crnn_loaded = true;
+}
+
+// ------------------------------------------------------------------------------------------------ conv helper
+static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out,
+                     int out_cs, int cout_store, bool out_f32) {
+    if (c->arena.dry) return;
+    ConvArgs a{};
+    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
+    if (a1) { a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C; }
+    a.N = a0.N; a.H = a0.H; a.W = a0.W;
+    a.relu_in0 = relu0; a.relu_in1 = relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
+    a.out = out; a.out_cs = out_cs; a.cout_store = cout_store;
+    HIPCHK(launch_conv(p, a, c->stream));
+}
+
+// conv producing a fresh bf16 activation with `store` channels (multiple of 16)
+static Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, int store) {
+    const int OH = a0.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a0.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
+    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * store), a0.N, OH, OW, store};
+    run_conv(c, p, a0, relu0, a1, relu1, relu_out, o.p, store, store, false);
+    return o;
+}
+
+static Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, int ph, int pw, bool relu_in) {
+    const int OH = (a.H + 2 * ph - kh) / sh + 1, OW = (a.W + 2 * pw - kw) / sw + 1;
+    Act o{c->arena.alloc<uint16_t>((size_t)a.N * OH * OW * a.C), a.N, OH, OW, a.C};
+    if (!c->arena.dry) HIPCHK(launch_maxpool(a.p, o.p, a.N, a.H, a.W, a.C, kh, kw, sh, sw, ph, pw, relu_in, c->stream));
+    return o;
+}
+
+static Act up_act(bbocr_ctx* c, const Act& a) {
+    Act o{c->arena.alloc<uint16_t>((size_t)a.N * 4 * a.H * a.W * a.C), a.N, 2 * a.H, 2 * a.W, a.C};
+    if (!c->arena.dry) HIPCHK(launch_upsample2x(a.p, o.p, a.N, a.H, a.W, a.C, c->stream));
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------ detector
+// rgb: [nb, Himg, Wimg, 3] on a zero canvas H32 x W32 -> heat fp32 [nb, H32/2, W32/2, 2]
+static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
+    Arena& ar = c->arena;
+    Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
+    if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->stream));
+    Act a2 = conv_act(c, c->conv1_2, a1, false, nullptr, false, true, 64);
+    Act p1 = pool_act(c, a2, 2, 2, 2, 2, 0, 0, false);
+    Act a3 = conv_act(c, c->conv2_1, p1, false, nullptr, false, true, 128);
+    Act s1 = conv_act(c, c->conv2_2, a3, false, nullptr, false, false, 128);      // slice1 ends on BatchNorm
+    Act p2 = pool_act(c, s1, 2, 2, 2, 2, 0, 0, true);                              // slice2 opens with ReLU, pool
+    Act a5 = conv_act(c, c->conv3_1, p2, false, nullptr, false, true, 256);
+    Act s2 = conv_act(c, c->conv3_2, a5, false, nullptr, false, false, 256);
+    Act a7 = conv_act(c, c->conv3_3, s2, true, nullptr, false, true, 256);         // ReLU applied on load
+    Act p3 = pool_act(c, a7, 2, 2, 2, 2, 0, 0, false);
+    Act a8 = conv_act(c, c->conv4_1, p3, false, nullptr, false, true, 512);
+    Act s3 = conv_act(c, c->conv4_2, a8, false, nullptr, false, false, 512);
+    Act a10 = conv_act(c, c->conv4_3, s3, true, nullptr, false, true, 512);
+    Act p4 = pool_act(c, a10, 2, 2, 2, 2, 0, 0, false);
+    Act a11 = conv_act(c, c->conv5_1, p4, false, nullptr, false, true, 512);
+    Act s4 = conv_act(c, c->conv5_2, a11, false, nullptr, false, false, 512);
+    Act p5 = pool_act(c, s4, 3, 3, 1, 1, 1, 1, false);                             // slice5: MaxPool(3,1,1), no ReLU
+    Act f6 = conv_act(c, c->fc6, p5, false, nullptr, false, false, 1024);
+    Act f7 = conv_act(c, c->fc7, f6, false, nullptr, false, false, 1024);
+    Act u1a = conv_act(c, c->up1a, f7, false, &s4, false, true, 512);              // cat([fc7, relu5_3]) -> 1x1
+    Act u1b = conv_act(c, c->up1b, u1a, false, nullptr, false, true, 256);
+    Act x1 = up_act(c, u1b);
+    Act u2a = conv_act(c, c->up2a, x1, false, &s3, false, true, 256);
+    Act u2b = conv_act(c, c->up2b, u2a, false, nullptr, false, true, 128);
+    Act x2 = up_act(c, u2b);
+    Act u3a = conv_act(c, c->up3a, x2, false, &s2, false, true, 128);
+    Act u3b = conv_act(c, c->up3b, u3a, false, nullptr, false, true, 64);
+    Act x3 = up_act(c, u3b);
+    Act u4a = conv_act(c, c->up4a, x3, false, &s1, false, true, 64);
+    Act u4b = conv_act(c, c->up4b, u4a, false, nullptr, false, true, 32);
+    Act c1 = conv_act(c, c->cls0, u4b, false, nullptr, false, true, 32);
+    Act c2 = conv_act(c, c->cls2, c1, false, nullptr, false, true, 32);
+    Act c3 = conv_act(c, c->cls4, c2, false, nullptr, false, true, 16);
+    if (!ar.dry)
+        HIPCHK(launch_cls_tail(c3.p, c->cls_tail, c->cls_tail + 256, c->cls_tail + 272, c->cls_tail + 304, heat,
+                               (size_t)nb * c3.H * c3.W, c->stream));
+}
+
+struct DetDims {
+    int H32, W32, h, w, th, tw;
+    double ratio;
+};
+static DetDims det_dims(int H, int W, int canvas, double mag) {
+    DetDims d;
+    double target = mag * (double)std::max(H, W);
+    if (target > canvas) target = canvas;
+    d.ratio = target / (double)std::max(H, W);
+    d.th = (int)(H * d.ratio);
+    d.tw = (int)(W * d.ratio);
+    d.H32 = d.th % 32 ? d.th + (32 - d.th % 32) : d.th;
+    d.W32 = d.tw % 32 ? d.tw + (32 - d.tw % 32) : d.tw;
+    d.h = d.H32 / 2;
+    d.w = d.W32 / 2;
+    return d;
+}
+
+static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bbocr_params& p, float* heat) {
+    if (!c->craft_loaded) fail(BBOCR_ERR_STATE, "detector weights not loaded");
+    if (B <= 0 || H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad page batch shape");
+    const DetDims d = det_dims(H, W, p.canvas_size, p.mag_ratio);
+    if (d.th <= 0 || d.tw <= 0) fail(BBOCR_ERR_ARG, "page collapses to zero size");
+    const int sb = c->cfg.det_sub_batch > 0 ? c->cfg.det_sub_batch : 8;
+    const bool need_resize = (d.th != H || d.tw != W);
+    if (need_resize) c->resized.ensure((size_t)std::min(sb, B) * d.th * d.tw * 3);
+    const int nb0 = std::min(sb, B);
+    c->arena.begin(true);
+    craft_forward(c, nullptr, nb0, d.th, d.tw, d.H32, d.W32, nullptr);
+    c->arena.buf.ensure(c->arena.off);
+    for (int b0 = 0; b0 < B; b0 += sb) {
+        const int nb = std::min(sb, B - b0);
+        const uint8_t* src = rgb + (size_t)b0 * H * W * 3;
+        if (need_resize) {
+            HIPCHK(launch_resize_u8(src, nb, H, W, 3, (uint8_t*)c->resized.p, d.th, d.tw, c->stream));
+            src = (const uint8_t*)c->resized.p;
+        }
+        c->arena.begin(false);
+        craft_forward(c, src, nb, d.th, d.tw, d.H32, d.W32, heat + (size_t)b0 * d.h * d.w * 2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ boxes
+struct HostBoxes {
+    std::vector<std::vector<std::array<int, 8>>> polys;
+    std::vector<std::vector<std::array<int, 4>>> hori;
+    std::vector<std::vector<std::array<double, 8>>> freeb;
+};
+
+static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double ratio, const bbocr_params& p, HostBoxes& hb) {
+    if (B <= 0 || h <= 0 || w <= 0 || !(ratio > 0)) fail(BBOCR_ERR_ARG, "bad heat-map shape");
+    const size_t npx = (size_t)B * h * w;
+    const int cap_comps = std::max(1024, h * w / 64), cap_rows = std::max(4096, h * w / 4);
+    c->ccl_label.ensure(npx * 4);
+    c->ccl_stat.ensure(npx * 24);
+    c->ccl_slot.ensure(npx * 4);
+    c->ccl_comps.ensure((size_t)B * cap_comps * sizeof(CclOut));
+    c->ccl_rowext.ensure((size_t)B * cap_rows * 8);
+    c->ccl_counters.ensure((size_t)B * 16);
+    auto t0 = clk::now();
+    HIPCHK(launch_ccl(heat, B, h, w, (float)p.low_text, (float)p.link_threshold, (double)p.text_threshold, (int*)c->ccl_label.p,
+                      (int*)c->ccl_stat.p, (int*)c->ccl_slot.p, (CclOut*)c->ccl_comps.p, (int*)c->ccl_rowext.p, (int*)c->ccl_counters.p,
+                      cap_comps, cap_rows, c->stream));
+    std::vector<int> counters((size_t)B * 4);
+    HIPCHK(hipMemcpyAsync(counters.data(), c->ccl_counters.p, counters.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<std::vector<CclOut>> comps(B);
+    std::vector<std::vector<int>> rows(B);
+    for (int b = 0; b < B; ++b) {
+        if (counters[b * 4 + 2]) fail(BBOCR_ERR_OVERFLOW, "component buffers too small for page " + std::to_string(b));
+        const int nc = counters[b * 4], nr = counters[b * 4 + 1];
+        comps[b].resize(nc);
+        rows[b].resize((size_t)nr * 2);
+        if (nc) HIPCHK(hipMemcpyAsync(comps[b].data(), (CclOut*)c->ccl_comps.p + (size_t)b * cap_comps, nc * sizeof(CclOut), hipMemcpyDeviceToHost, c->stream));
+        if (nr) HIPCHK(hipMemcpyAsync(rows[b].data(), (int*)c->ccl_rowext.p + (size_t)b * cap_rows * 2, (size_t)nr * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->times[1] += (float)ms_since(t0);
+    t0 = clk::now();
+    const double ratio_w = 1.0 / ratio, ratio_h = 1.0 / ratio;
+    bbocr::GroupParams gp{p.slope_ths, p.ycenter_ths, p.height_ths, p.width_ths, p.add_margin, p.min_size};
+    hb.polys.assign(B, {});
+    hb.hori.assign(B, {});
+    hb.freeb.assign(B, {});
+    for (int b = 0; b < B; ++b) {
+        std::sort(comps[b].begin(), comps[b].end(), [](const CclOut& x, const CclOut& y) { return x.root < y.root; });
+        for (const CclOut& co : comps[b]) {
+            bbocr::Component cc{co.root, co.left, co.top, co.right, co.bottom, co.area, co.row_off};
+            float box[4][2];
+            bbocr::component_box(cc, rows[b].data() + (size_t)co.row_off * 2, w, h, box);
+            std::array<int, 8> poly;
+            bbocr::box_to_poly(box, ratio_w, ratio_h, poly.data());
+            hb.polys[b].push_back(poly);
+        }
+        bbocr::group_text_box(hb.polys[b], gp, hb.hori[b], hb.freeb[b]);
+    }
+    c->times[2] += (float)ms_since(t0);
+}
+
+static bbocr_boxlist* export_boxes(const HostBoxes& hb) {
+    const int B = (int)hb.polys.size();
+    bbocr_boxlist* o = (bbocr_boxlist*)calloc(1, sizeof(bbocr_boxlist));
+    o->n_images = B;
+    o->poly_off = (int*)calloc(B + 1, sizeof(int));
+    o->hori_off = (int*)calloc(B + 1, sizeof(int));
+    o->free_off = (int*)calloc(B + 1, sizeof(int));
+    for (int b = 0; b < B; ++b) {
+        o->poly_off[b + 1] = o->poly_off[b] + (int)hb.polys[b].size();
+        o->hori_off[b + 1] = o->hori_off[b] + (int)hb.hori[b].size();
+        o->free_off[b + 1] = o->free_off[b] + (int)hb.freeb[b].size();
+    }
+    o->polys = (int*)calloc((size_t)std::max(1, o->poly_off[B]) * 8, sizeof(int));
+    o->hori = (int*)calloc((size_t)std::max(1, o->hori_off[B]) * 4, sizeof(int));
+    o->free_q = (double*)calloc((size_t)std::max(1, o->free_off[B]) * 8, sizeof(double));
+    for (int b = 0; b < B; ++b) {
+        for (size_t i = 0; i < hb.polys[b].size(); ++i) memcpy(o->polys + ((size_t)o->poly_off[b] + i) * 8, hb.polys[b][i].data(), 32);
+        for (size_t i = 0; i < hb.hori[b].size(); ++i) memcpy(o->hori + ((size_t)o->hori_off[b] + i) * 4, hb.hori[b][i].data(), 16);
+        for (size_t i = 0; i < hb.freeb[b].size(); ++i) memcpy(o->free_q + ((size_t)o->free_off[b] + i) * 8, hb.freeb[b][i].data(), 64);
+    }
+    return o;
+}
+
+static void import_boxes(const bbocr_boxlist* bl, HostBoxes& hb) {
+    const int B = bl->n_images;
+    hb.polys.assign(B, {});
+    hb.hori.assign(B, {});
+    hb.freeb.assign(B, {});
+    for (int b = 0; b < B; ++b) {
+        for (int i = bl->hori_off[b]; i < bl->hori_off[b + 1]; ++i) {
+            std::array<int, 4> a;
+            memcpy(a.data(), bl->hori + (size_t)i * 4, 16);
+            hb.hori[b].push_back(a);
+        }
+        for (int i = bl->free_off[b]; i < bl->free_off[b + 1]; ++i) {
+            std::array<double, 8> a;
+            memcpy(a.data(), bl->free_q + (size_t)i * 8, 64);
+            hb.freeb[b].push_back(a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ recogniser
+struct BoxJob {            // one box to recognise
+    int img;
+    bool is_free;
+    double quad[8];        // reported corners
+    CropDesc d;
+    std::vector<int> text;
+    double conf = 0.0;
+};
+
+// AlignCollate / get_image_list geometry of one horizontal box; false = skipped (degenerate)
+static bool plan_horizontal(const std::array<int, 4>& box, int img, int H, int W, BoxJob& j) {
+    const int x_min = std::max(0, box[0]), x_max = std::min(box[1], W), y_min = std::max(0, box[2]), y_max = std::min(box[3], H);
+    const int width = x_max - x_min, height = y_max - y_min;
+    if (width <= 0 || height <= 0) return false;
+    j.img = img;
+    j.is_free = false;
+    const double q[8] = {(double)x_min, (double)y_min, (double)x_max, (double)y_min, (double)x_max, (double)y_max, (double)x_min, (double)y_max};
+    memcpy(j.quad, q, sizeof(q));
+    CropDesc& d = j.d;
+    memset(&d, 0, sizeof(d));
+    d.img = img; d.sx0 = x_min; d.sy0 = y_min; d.sw = width; d.sh = height; d.warp = 0; d.lut_off = -1;
+    double ratio = (double)width / (double)height;
+    if (ratio < 1.0) {
+        ratio = 1.0 / ratio;
+        d.rw = 64; d.rh = (int)(64 * ratio);
+    } else {
+        d.rw = (int)(64 * ratio); d.rh = 64;
+    }
+    if ((int)(64 * ratio) == 0) return false;
+    d.imgW = (int)std::ceil(std::max(ratio, 1.0)) * 64;
+    const double r2 = (double)d.rw / (double)d.rh;
+    const int cw = (int)std::ceil(64 * r2);
+    d.fw = cw > d.imgW ? d.imgW : cw;
+    return d.rw > 0 && d.rh > 0 && d.fw > 0;
+}
+
+static bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j) {
+    float rect[4][2];
+    for (int i = 0; i < 4; ++i) { rect[i][0] = (float)fq[2 * i]; rect[i][1] = (float)fq[2 * i + 1]; }
+    auto dist = [&](int a, int b) {
+        const float dx = rect[a][0] - rect[b][0], dy = rect[a][1] - rect[b][1];
+        const float t0 = dx * dx, t1 = dy * dy;
+        return std::sqrt(t0 + t1);   // float32, as numpy on a float32 array
+    };
+    const int maxW = std::max((int)dist(2, 3), (int)dist(1, 0));
+    const int maxH = std::max((int)dist(1, 2), (int)dist(0, 3));
+    if (maxW <= 0 || maxH <= 0) return false;
+    j.img = img;
+    j.is_free = true;
+    memcpy(j.quad, fq.data(), 64);
+    CropDesc& d = j.d;
+    memset(&d, 0, sizeof(d));
+    d.img = img; d.sx0 = 0; d.sy0 = 0; d.sw = maxW; d.sh = maxH; d.warp = 1; d.lut_off = -1;
+    bbocr::perspective_inverse(rect, maxW, maxH, d.Minv);
+    double ratio = (double)maxW / (double)maxH;
+    if (ratio < 1.0) {
+        ratio = 1.0 / ratio;
+        d.rw = 64; d.rh = (int)(64 * ratio);
+    } else {
+        d.rw = (int)(64 * ratio); d.rh = 64;
+    }
+    if ((int)(64 * ratio) == 0) return false;
+    d.imgW = (int)std::ceil(std::max(ratio, 1.0)) * 64;
+    const double r2 = (double)d.rw / (double)d.rh;
+    const int cw = (int)std::ceil(64 * r2);
+    d.fw = cw > d.imgW ? d.imgW : cw;
+    return d.rw > 0 && d.rh > 0 && d.fw > 0;
+}
+
+// CRNN forward for n normalised crops bf16 [n,64,imgW] -> logits fp32 [n,T,112]
+static void crnn_forward(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, float* logits) {
+    Arena& ar = c->arena;
+    const int T = imgW / 4 - 1;
+    Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32), n, 32, imgW / 2, 32};
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->stream));
+    Act c1 = conv_act(c, c->r1, c0, false, nullptr, false, true, 64);
+    Act q1 = pool_act(c, c1, 2, 2, 2, 2, 0, 0, false);
+    Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
+    Act c3 = conv_act(c, c->r3, c2, false, nullptr, false, true, 128);
+    Act q2 = pool_act(c, c3, 2, 1, 2, 1, 0, 0, false);
+    Act c4 = conv_act(c, c->r4, q2, false, nullptr, false, true, 256);
+    Act c5 = conv_act(c, c->r5, c4, false, nullptr, false, true, 256);
+    Act q3 = pool_act(c, c5, 2, 1, 2, 1, 0, 0, false);
+    Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [n,3,T,256]
+    Act v{ar.alloc<uint16_t>((size_t)n * T * 256), 1, n, T, 256};           // sequences as rows of one "image"
+    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v.p, n, T, 256, c->stream));
+    Act cur = v;
+    for (int l = 0; l < 2; ++l) {
+        Act xp = conv_act(c, c->xproj[l], cur, false, nullptr, false, false, 2048);
+        Act hh{ar.alloc<uint16_t>((size_t)n * T * 512), 1, n, T, 512};
+        if (!ar.dry) HIPCHK(launch_lstm(xp.p, c->whh[l], hh.p, n, T, c->stream));
+        cur = conv_act(c, c->lin[l], hh, false, nullptr, false, false, 256);
+    }
+    run_conv(c, c->pred, cur, false, nullptr, false, false, logits, 112, 112, true);
+}
+
+struct Bucket {
+    int imgW;
+    std::vector<int> jobs;   // indices into the job array
+};
+
+// run one recognition pass over `sel` (indices into jobs); descs must already carry lut_off for a contrast pass.
+static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std::vector<BoxJob>& jobs, const std::vector<int>& sel,
+                           bool stage_a, std::vector<std::vector<int>>& texts, std::vector<double>& confs) {
+    texts.assign(sel.size(), {});
+    confs.assign(sel.size(), 0.0);
+    if (sel.empty()) return;
+    // bucket by padded width, keep box order inside a bucket
+    std::map<int, std::vector<int>> buckets;
+    for (size_t k = 0; k < sel.size(); ++k) buckets[jobs[sel[k]].d.imgW].push_back((int)k);
+    // descriptor table in bucket order
+    std::vector<CropDesc> descs;
+    std::vector<int> order;   // position k in sel for each descriptor
+    descs.reserve(sel.size());
+    for (auto& kv : buckets)
+        for (int k : kv.second) { descs.push_back(jobs[sel[k]].d); order.push_back(k); }
+    const int max_cols = c->cfg.rec_max_cols > 0 ? c->cfg.rec_max_cols : 262144;
+    c->crop_desc.ensure(descs.size() * sizeof(CropDesc));
+    auto t0 = clk::now();
+    size_t pos = 0;
+    for (auto& kv : buckets) {
+        const int imgW = kv.first, T = imgW / 4 - 1;
+        const int per = std::max(1, max_cols / imgW);
+        for (size_t s0 = 0; s0 < kv.second.size(); s0 += per) {
+            const int n = (int)std::min<size_t>(per, kv.second.size() - s0);
+            for (int i = 0; i < n; ++i) descs[pos + s0 + i].slot = i;
+        }
+        pos += kv.second.size();
+    }
+    HIPCHK(hipMemcpyAsync(c->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
+    bool any_warp = false, any_tall = false;
+    for (const CropDesc& d : descs) {
+        any_warp |= d.warp != 0;
+        any_tall |= !(d.fw == d.rw && d.rh == 64);
+    }
+    if (stage_a)
+        HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, 0, (int)descs.size(), 0, any_warp, any_tall, (uint8_t*)c->crop_wscratch.p,
+                            (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, nullptr, 1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->times[3] += (float)ms_since(t0);
+    pos = 0;
+    for (auto& kv : buckets) {
+        const int imgW = kv.first, T = imgW / 4 - 1;
+        const int per = std::max(1, max_cols / imgW);
+        for (size_t s0 = 0; s0 < kv.second.size(); s0 += per) {
+            const int n = (int)std::min<size_t>(per, kv.second.size() - s0);
+            const int first = (int)(pos + s0);
+            // size the arena, then run
+            uint16_t* crops = nullptr;
+            float* logits = nullptr;
+            for (int pass = 0; pass < 2; ++pass) {
+                c->arena.begin(pass == 0);
+                crops = c->arena.alloc<uint16_t>((size_t)n * 64 * imgW);
+                logits = c->arena.alloc<float>((size_t)n * T * 112);
+                if (pass == 1) {
+                    t0 = clk::now();
+                    HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, first, n, imgW, any_warp, any_tall,
+                                        (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
+                                        (const uint8_t*)c->crop_luts.p, crops, 2, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    c->times[3] += (float)ms_since(t0);
+                    t0 = clk::now();
+                }
+                crnn_forward(c, crops, n, imgW, logits);
+                if (pass == 0) c->arena.buf.ensure(c->arena.off);
+            }
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->times[4] += (float)ms_since(t0);
+            t0 = clk::now();
+            c->ctc_idx.ensure((size_t)n * T * 4);
+            c->ctc_pmax.ensure((size_t)n * T * 4);
+            c->ctc_out_idx.ensure((size_t)n * T * 4);
+            c->ctc_out.ensure((size_t)n * sizeof(CtcOut));
+            HIPCHK(launch_ctc(logits, n, T, 97, 112, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p, (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p,
+                              c->stream));
+            std::vector<int> oidx((size_t)n * T);
+            std::vector<CtcOut> oo(n);
+            HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < n; ++i) {
+                const int k = order[first + i];
+                texts[k].assign(oidx.begin() + (size_t)i * T, oidx.begin() + (size_t)i * T + oo[i].len);
+                // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
+                confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
+            }
+            c->times[5] += (float)ms_since(t0);
+        }
+        pos += kv.second.size();
+    }
+}
+
+// np.percentile(img, q) (method 'linear') from a 256-bin histogram of n uint8 samples
+static double percentile_u8(const unsigned int* hist, size_t n, double q) {
+    const double virt = (double)(n - 1) * (q / 100.0);
+    const double prev = std::floor(virt);
+    const double gamma = virt - prev;
+    const size_t i0 = (size_t)prev, i1 = std::min(i0 + 1, n - 1);
+    auto at = [&](size_t idx) {
+        size_t acc = 0;
+        for (int v = 0; v < 256; ++v) {
+            acc += hist[v];
+            if (idx < acc) return v;
+        }
+        return 255;
+    };
+    const int a = at(i0), b = at(i1);
+    const double diff = (double)(b - a);
+    double r = (double)a + diff * gamma;
+    if (gamma >= 0.5) r = (double)b - diff * (1 - gamma);
+    return r;
+}
+
+static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p,
+                           std::vector<BoxJob>& jobs, std::vector<int>& box_off) {
+    if (!c->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
+    jobs.clear();
+    box_off.assign(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        for (const auto& hbx : hb.hori[b]) {
+            BoxJob j;
+            if (plan_horizontal(hbx, b, H, W, j)) jobs.push_back(j);
+        }
+        for (const auto& fq : hb.freeb[b]) {
+            BoxJob j;
+            if (plan_free(fq, b, j)) jobs.push_back(j);
+        }
+        box_off[b + 1] = (int)jobs.size();
+    }
+    if (jobs.empty()) return;
+    // scratch layout
+    size_t a_total = 0, w_total = 0;
+    for (BoxJob& j : jobs) {
+        j.d.a_off = (int)a_total;
+        a_total += align_up((size_t)j.d.rw * j.d.rh, 16);
+        if (j.d.warp) {
+            j.d.warp_off = (int)w_total;
+            w_total += align_up((size_t)j.d.sw * j.d.sh, 16);
+        }
+        if (a_total > 0x7fffffff || w_total > 0x7fffffff) fail(BBOCR_ERR_OVERFLOW, "crop scratch exceeds 2 GiB");
+    }
+    c->crop_scratch.ensure(std::max<size_t>(a_total, 16));
+    c->crop_hscratch.ensure(std::max<size_t>(a_total, 16));
+    c->crop_wscratch.ensure(std::max<size_t>(w_total, 16));
+    c->crop_luts.ensure(256);
+    std::vector<int> all(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) all[i] = (int)i;
+    std::vector<std::vector<int>> texts;
+    std::vector<double> confs;
+    recognise_pass(c, gray, H, W, jobs, all, true, texts, confs);
+    for (size_t i = 0; i < jobs.size(); ++i) { jobs[i].text = texts[i]; jobs[i].conf = confs[i]; }
+    // second round: adjust_contrast_grey for low-confidence boxes
+    std::vector<int> low;
+    for (size_t i = 0; i < jobs.size(); ++i)
+        if (jobs[i].conf < p.contrast_ths) low.push_back((int)i);
+    if (low.empty() || !(p.adjust_contrast > 0)) return;
+    auto t0 = clk::now();
+    std::vector<CropDesc> ld(low.size());
+    for (size_t k = 0; k < low.size(); ++k) ld[k] = jobs[low[k]].d;
+    c->crop_desc.ensure(ld.size() * sizeof(CropDesc));
+    c->crop_hist.ensure(ld.size() * 256 * 4);
+    HIPCHK(hipMemcpyAsync(c->crop_desc.p, ld.data(), ld.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_crop_hist((const uint8_t*)c->crop_scratch.p, (const CropDesc*)c->crop_desc.p, 0, (int)ld.size(), (unsigned int*)c->crop_hist.p,
+                            c->stream));
+    std::vector<unsigned int> hist(ld.size() * 256);
+    HIPCHK(hipMemcpyAsync(hist.data(), c->crop_hist.p, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> luts(low.size() * 256);
+    for (size_t k = 0; k < low.size(); ++k) {
+        const size_t npx = (size_t)ld[k].rw * ld[k].rh;
+        const double high = percentile_u8(&hist[k * 256], npx, 90.0), lowp = percentile_u8(&hist[k * 256], npx, 10.0);
+        const double contrast = (high - lowp) / std::max(10.0, high + lowp);
+        uint8_t* lut = &luts[k * 256];
+        if (contrast < p.adjust_contrast) {
+            const double ratio = 200.0 / std::max(10.0, high - lowp);
+            for (int v = 0; v < 256; ++v) {
+                double x = ((double)v - lowp + 25) * ratio;
+                x = std::max(0.0, std::min(255.0, x));
+                lut[v] = (uint8_t)x;
+            }
+        } else {
+            for (int v = 0; v < 256; ++v) lut[v] = (uint8_t)v;
+        }
+        jobs[low[k]].d.lut_off = (int)(k * 256);
+    }
+    c->crop_luts.ensure(luts.size());
+    HIPCHK(hipMemcpyAsync(c->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<std::vector<int>> t2;
+    std::vector<double> c2;
+    recognise_pass(c, gray, H, W, jobs, low, false, t2, c2);
+    for (size_t k = 0; k < low.size(); ++k) {
+        BoxJob& j = jobs[low[k]];
+        j.d.lut_off = -1;
+        if (!(j.conf > c2[k])) { j.text = t2[k]; j.conf = c2[k]; }
+    }
+    c->times[6] += (float)ms_since(t0);
+}
+
+static bbocr_result* export_result(int B, const std::vector<BoxJob>& jobs, const std::vector<int>& box_off) {
+    bbocr_result* r = (bbocr_result*)calloc(1, sizeof(bbocr_result));
+    const size_t nb = jobs.size();
+    r->n_images = B;
+    r->box_off = (int*)calloc(B + 1, sizeof(int));
+    for (int b = 0; b <= B; ++b) r->box_off[b] = box_off[b];
+    r->quads = (double*)calloc(std::max<size_t>(1, nb) * 8, sizeof(double));
+    r->is_free = (int*)calloc(std::max<size_t>(1, nb), sizeof(int));
+    r->text_off = (int*)calloc(nb + 1, sizeof(int));
+    r->conf = (double*)calloc(std::max<size_t>(1, nb), sizeof(double));
+    size_t nt = 0;
+    for (const BoxJob& j : jobs) nt += j.text.size();
+    r->text_idx = (int*)calloc(std::max<size_t>(1, nt), sizeof(int));
+    size_t o = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        memcpy(r->quads + i * 8, jobs[i].quad, 64);
+        r->is_free[i] = jobs[i].is_free;
+        r->conf[i] = jobs[i].conf;
+        r->text_off[i] = (int)o;
+        for (int v : jobs[i].text) r->text_idx[o++] = v;
+    }
+    r->text_off[nb] = (int)o;
+    return r;
+}
+
+template <typename F> static int guarded(bbocr_ctx* ctx, F&& f) {
+    if (!ctx) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    try {
+        hipError_t e = hipSetDevice(ctx->cfg.device);
+        if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        f();
+        return BBOCR_OK;
+    } catch (const StatusError& se) {
+        ctx->err = se.msg;
+        (void)hipGetLastError();
+        return se.code;
+    } catch (const std::exception& ex) {
+        ctx->err = ex.what();
+        return BBOCR_ERR_INTERNAL;
+    } catch (...) {
+        ctx->err = "unknown failure";
+        return BBOCR_ERR_INTERNAL;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+void bbocr_default_params(bbocr_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->text_threshold = 0.7; p->low_text = 0.4; p->link_threshold = 0.4; p->canvas_size = 2560; p->mag_ratio = 1.0;
+    p->slope_ths = 0.1; p->ycenter_ths = 0.5; p->height_ths = 0.5; p->width_ths = 0.5; p->add_margin = 0.1; p->min_size = 20;
+    p->contrast_ths = 0.1; p->adjust_contrast = 0.5;
+}
+
+int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
+    if (!out) return BBOCR_ERR_ARG;
+    *out = nullptr;
+    bbocr_ctx* c = nullptr;
+    try {
+        c = new bbocr_ctx();
+        if (cfg) c->cfg = *cfg;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->cfg.device < 0 || c->cfg.device >= ndev) {
+            delete c;
+            return BBOCR_ERR_HIP;
+        }
+        if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return BBOCR_ERR_HIP;
+        }
+    } catch (...) {
+        delete c;
+        return BBOCR_ERR_INTERNAL;
+    }
+    *out = c;
+    return BBOCR_OK;
+}
+
+void bbocr_destroy(bbocr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_weights(c);
+    DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
+                      &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
+                      &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out};
+    for (DevBuf* b : bufs) b->release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bbocr_last_error(bbocr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n) {
+    return guarded(ctx, [&] {
+        if (!descs || n <= 0 || (which != 0 && which != 1)) fail(BBOCR_ERR_ARG, "bad weight descriptor table");
+        TensorMap tm(descs, n);
+        if (which == 0) load_craft(ctx, tm);
+        else load_crnn(ctx, tm);
+    });
+}
+
+int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio) {
+    if (H <= 0 || W <= 0 || canvas_size <= 0) return BBOCR_ERR_ARG;
+    const DetDims d = det_dims(H, W, canvas_size, (double)mag_ratio);
+    if (H32) *H32 = d.H32;
+    if (W32) *W32 = d.W32;
+    if (rh) *rh = d.h;
+    if (rw) *rw = d.w;
+    if (ratio) *ratio = d.ratio;
+    return BBOCR_OK;
+}
+
+int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, const bbocr_params* p, float* dev_heat_out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_rgb || !dev_heat_out) fail(BBOCR_ERR_ARG, "null device pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        detect_impl(ctx, dev_rgb, B, H, W, pp, dev_heat_out);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->times[0] = ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, double ratio, const bbocr_params* p, bbocr_boxlist** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_heat || !out) fail(BBOCR_ERR_ARG, "null pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        HostBoxes hb;
+        boxes_impl(ctx, dev_heat, B, h, w, ratio, pp, hb);
+        *out = export_boxes(hb);
+        ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W, const bbocr_boxlist* boxes, const bbocr_params* p,
+                    bbocr_result** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_gray || !boxes || !out || boxes->n_images != B) fail(BBOCR_ERR_ARG, "bad recognise arguments");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        HostBoxes hb;
+        import_boxes(boxes, hb);
+        std::vector<BoxJob> jobs;
+        std::vector<int> off;
+        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        *out = export_result(B, jobs, off);
+        ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* dev_gray, int B, int H, int W, const bbocr_params* p,
+                         bbocr_result** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_rgb || !out) fail(BBOCR_ERR_ARG, "null pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t_all = clk::now();
+        const DetDims d = det_dims(H, W, pp.canvas_size, pp.mag_ratio);
+        ctx->heat.ensure((size_t)B * d.h * d.w * 2 * sizeof(float));
+        if (!dev_gray) {
+            ctx->gray.ensure((size_t)B * H * W);
+            HIPCHK(launch_gray(dev_rgb, (uint8_t*)ctx->gray.p, (size_t)B * H * W, ctx->stream));
+            dev_gray = (const uint8_t*)ctx->gray.p;
+        }
+        auto t0 = clk::now();
+        detect_impl(ctx, dev_rgb, B, H, W, pp, (float*)ctx->heat.p);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->times[0] = (float)ms_since(t0);
+        HostBoxes hb;
+        boxes_impl(ctx, (const float*)ctx->heat.p, B, d.h, d.w, d.ratio, pp, hb);
+        std::vector<BoxJob> jobs;
+        std::vector<int> off;
+        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        *out = export_result(B, jobs, off);
+        ctx->times[7] = (float)ms_since(t_all);
+    });
+}
+
+void bbocr_free_boxlist(bbocr_boxlist* b) {
+    if (!b) return;
+    free(b->poly_off); free(b->polys); free(b->hori_off); free(b->hori); free(b->free_off); free(b->free_q);
+    free(b);
+}
+
+void bbocr_free_result(bbocr_result* r) {
+    if (!r) return;
+    free(r->box_off); free(r->quads); free(r->is_free); free(r->text_off); free(r->text_idx); free(r->conf);
+    free(r);
+}
+
+int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n) {
+    if (!ctx || !ms || n <= 0) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = ctx->times[i];
+    return BBOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------- single-operator entry points
+int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, int KH,
+                    int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out) {
+    return guarded(ctx, [&] {
+        if (!dev_in || !w || !dev_out || Cin <= 0 || (Cin & 31) || Cout <= 0 || KH <= 0 || KW <= 0) fail(BBOCR_ERR_ARG, "bad conv arguments");
+        ConvPlan p = make_plan(Cin, Cout, KH, KW, pad, dil);
+        std::vector<float> wv(w, w + (size_t)Cout * Cin * KH * KW), bv(Cout, 0.f);
+        if (bias) std::copy(bias, bias + Cout, bv.begin());
+        const size_t owned0 = ctx->owned.size();
+        upload_plan(ctx, p, wv, bv);
+        const int store = cdiv(Cout, 16) * 16;
+        Act a{const_cast<uint16_t*>(dev_in), N, H, W, Cin};
+        ctx->arena.dry = false;
+        run_conv(ctx, p, a, relu_in != 0, nullptr, false, relu_out != 0, dev_out, store, store, out_f32 != 0);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); }
+    });
+}
+
+int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits) {
+    return guarded(ctx, [&] {
+        if (!ctx->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
+        if (!dev_crops || !dev_logits || n <= 0 || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop batch");
+        ctx->arena.begin(true);
+        crnn_forward(ctx, dev_crops, n, imgW, dev_logits);
+        ctx->arena.buf.ensure(ctx->arena.off);
+        ctx->arena.begin(false);
+        crnn_forward(ctx, dev_crops, n, imgW, dev_logits);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf) {
+    return guarded(ctx, [&] {
+        if (!dev_logits || !text_off || !text_idx || !conf || n <= 0 || T <= 0 || C <= 0 || C > cs) fail(BBOCR_ERR_ARG, "bad ctc arguments");
+        ctx->ctc_idx.ensure((size_t)n * T * 4);
+        ctx->ctc_pmax.ensure((size_t)n * T * 4);
+        ctx->ctc_out_idx.ensure((size_t)n * T * 4);
+        ctx->ctc_out.ensure((size_t)n * sizeof(CtcOut));
+        HIPCHK(launch_ctc(dev_logits, n, T, C, cs, (int*)ctx->ctc_idx.p, (float*)ctx->ctc_pmax.p, (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p,
+                          ctx->stream));
+        std::vector<int> oidx((size_t)n * T);
+        std::vector<CtcOut> oo(n);
+        HIPCHK(hipMemcpyAsync(oidx.data(), ctx->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(oo.data(), ctx->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        int o = 0;
+        for (int i = 0; i < n; ++i) {
+            text_off[i] = o;
+            for (int k = 0; k < oo[i].len; ++k) text_idx[o++] = oidx[(size_t)i * T + k];
+            conf[i] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
+        }
+        text_off[n] = o;
+    });
+}
+
+int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw) {
+    return guarded(ctx, [&] {
+        if (!dev_src || !dev_dst || N <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0) fail(BBOCR_ERR_ARG, "bad resize arguments");
+        HIPCHK(launch_resize_u8(dev_src, N, sh, sw, C, dev_dst, dh, dw, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free, int imgW,
+                   float contrast, uint16_t* dev_out, int* n_out) {
+    return guarded(ctx, [&] {
+        if (!dev_gray || !dev_out || !n_out || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop arguments");
+        std::vector<BoxJob> jobs;
+        for (int i = 0; i < n_hori; ++i) {
+            BoxJob j;
+            std::array<int, 4> b;
+            memcpy(b.data(), hori + (size_t)i * 4, 16);
+            if (plan_horizontal(b, 0, H, W, j) && j.d.imgW == imgW) jobs.push_back(j);
+        }
+        for (int i = 0; i < n_free; ++i) {
+            BoxJob j;
+            std::array<double, 8> f;
+            memcpy(f.data(), free_q + (size_t)i * 8, 64);
+            if (plan_free(f, 0, j) && j.d.imgW == imgW) jobs.push_back(j);
+        }
+        *n_out = (int)jobs.size();
+        if (jobs.empty()) return;
+        size_t a_total = 0, w_total = 0;
+        bool any_warp = false, any_tall = false;
+        std::vector<CropDesc> descs;
+        for (size_t i = 0; i < jobs.size(); ++i) {
+            CropDesc& d = jobs[i].d;
+            d.a_off = (int)a_total;
+            a_total += align_up((size_t)d.rw * d.rh, 16);
+            if (d.warp) { d.warp_off = (int)w_total; w_total += align_up((size_t)d.sw * d.sh, 16); }
+            d.slot = (int)i;
+            any_warp |= d.warp != 0;
+            any_tall |= !(d.fw == d.rw && d.rh == 64);
+        }
+        ctx->crop_scratch.ensure(std::max<size_t>(a_total, 16));
+        ctx->crop_hscratch.ensure(std::max<size_t>(a_total, 16));
+        ctx->crop_wscratch.ensure(std::max<size_t>(w_total, 16));
+        for (auto& j : jobs) descs.push_back(j.d);
+        ctx->crop_desc.ensure(descs.size() * sizeof(CropDesc));
+        ctx->crop_luts.ensure(descs.size() * 256);
+        HIPCHK(hipMemcpyAsync(ctx->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(launch_crops(dev_gray, H, W, (const CropDesc*)ctx->crop_desc.p, 0, (int)descs.size(), imgW, any_warp, any_tall,
+                            (uint8_t*)ctx->crop_wscratch.p, (uint8_t*)ctx->crop_scratch.p, (uint8_t*)ctx->crop_hscratch.p,
+                            (const uint8_t*)ctx->crop_luts.p, dev_out, 1, ctx->stream));
+        if (contrast > 0) {
+            ctx->crop_hist.ensure(descs.size() * 256 * 4);
+            HIPCHK(launch_crop_hist((const uint8_t*)ctx->crop_scratch.p, (const CropDesc*)ctx->crop_desc.p, 0, (int)descs.size(),
+                                    (unsigned int*)ctx->crop_hist.p, ctx->stream));
+            std::vector<unsigned int> hist(descs.size() * 256);
+            HIPCHK(hipMemcpyAsync(hist.data(), ctx->crop_hist.p, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::vector<uint8_t> luts(descs.size() * 256);
+            for (size_t k = 0; k < descs.size(); ++k) {
+                const size_t npx = (size_t)descs[k].rw * descs[k].rh;
+                const double high = percentile_u8(&hist[k * 256], npx, 90.0), lowp = percentile_u8(&hist[k * 256], npx, 10.0);
+                const double con = (high - lowp) / std::max(10.0, high + lowp);
+                for (int v = 0; v < 256; ++v) {
+                    if (con < (double)contrast) {
+                        double x = ((double)v - lowp + 25) * (200.0 / std::max(10.0, high - lowp));
+                        x = std::max(0.0, std::min(255.0, x));
+                        luts[k * 256 + v] = (uint8_t)x;
+                    } else {
+                        luts[k * 256 + v] = (uint8_t)v;
+                    }
+                }
+                descs[k].lut_off = (int)(k * 256);
+            }
+            HIPCHK(hipMemcpyAsync(ctx->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIPCHK(launch_crops(dev_gray, H, W, (const CropDesc*)ctx->crop_desc.p, 0, (int)descs.size(), imgW, any_warp, any_tall,
+                            (uint8_t*)ctx->crop_wscratch.p, (uint8_t*)ctx->crop_scratch.p, (uint8_t*)ctx->crop_hscratch.p,
+                            (const uint8_t*)ctx->crop_luts.p, dev_out, 2, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+}  // extern "C"

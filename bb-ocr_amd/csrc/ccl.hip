@@ -1,0 +1,135 @@
+// Region/affinity heat-map -> connected components (4-connectivity) with the statistics getDetBoxes_core needs.
+//
+// Restates the pixel-level part of easyocr/craft_utils.py::getDetBoxes_core (cv2.threshold, np.clip(text+link),
+// cv2.connectedComponentsWithStats(connectivity=4), per-label area / bbox / max(textmap), link-only pixel removal) as
+// label-equivalence union-find on the GPU.  The per-component geometry that follows (rect dilation, minAreaRect) only
+// depends on each component's per-row x-extremes of TEXT pixels, which is what this file emits; boxpost.cpp finishes
+// on the host.  A component's id is its smallest pixel index == OpenCV's raster-order label order.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ int ccl_find(const int* __restrict__ label, int x) {
+    int p = __hip_atomic_load(label + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(label + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
+__device__ __forceinline__ void ccl_union(int* label, int a, int b) {
+    for (;;) {
+        a = ccl_find(label, a);
+        b = ccl_find(label, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(label + b, a);   // b was a root iff old == b
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, size_t total, float low_text, float link_thr,
+                                                       int* __restrict__ label, int* __restrict__ stat, int* __restrict__ slot) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float2 v = *(const float2*)(heat + i * 2);
+        const bool fg = (v.x > low_text) || (v.y > link_thr);
+        label[i] = fg ? (int)i : -1;
+        slot[i] = -1;
+        int* st = stat + i * 6;
+        st[0] = 0x7fffffff; st[1] = -1; st[2] = 0x7fffffff; st[3] = -1; st[4] = 0; st[5] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_merge_kernel(size_t total, int h, int w, int* label) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (label[i] < 0) continue;
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        if (x > 0 && label[i - 1] >= 0) ccl_union(label, (int)i, (int)i - 1);
+        if (y > 0 && label[i - w] >= 0) ccl_union(label, (int)i, (int)i - w);
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_stats_kernel(const float* __restrict__ heat, size_t total, int h, int w, int* label,
+                                                        int* __restrict__ stat) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (label[i] < 0) continue;
+        const int r = ccl_find(label, (int)i);
+        label[i] = r;
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        int* st = stat + (size_t)r * 6;
+        atomicMin(st + 0, x);
+        atomicMax(st + 1, x);
+        atomicMin(st + 2, y);
+        atomicMax(st + 3, y);
+        atomicAdd(st + 4, 1);
+        const float t = heat[i * 2];
+        if (t > 0.f) atomicMax(st + 5, __float_as_int(t));
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_accept_kernel(size_t total, int hw, double text_thr, const int* __restrict__ label,
+                                                         const int* __restrict__ stat, int* __restrict__ slot, CclOut* comps,
+                                                         int* rowext, int* counters, int cap_comps, int cap_rows) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (label[i] != (int)i) continue;
+        const int* st = stat + i * 6;
+        const int area = st[4];
+        if (area < 10) continue;
+        // upstream compares the float32 maximum with the Python float 0.7 in double precision
+        if ((double)__int_as_float(st[5]) < text_thr) continue;
+        const int img = (int)(i / hw);
+        int* cnt = counters + img * 4;
+        const int hh = st[3] - st[2] + 1;
+        const int idx = atomicAdd(cnt + 0, 1);
+        const int off = atomicAdd(cnt + 1, hh);
+        if (idx >= cap_comps || off + hh > cap_rows) { atomicOr(cnt + 2, 1); continue; }
+        CclOut c;
+        c.root = (int)(i - (size_t)img * hw);
+        c.left = st[0]; c.top = st[2]; c.right = st[1]; c.bottom = st[3]; c.area = area; c.row_off = off; c.pad = 0;
+        comps[(size_t)img * cap_comps + idx] = c;
+        slot[i] = idx;
+        int* re = rowext + ((size_t)img * cap_rows + off) * 2;
+        for (int k = 0; k < hh; ++k) { re[2 * k] = 0x7fffffff; re[2 * k + 1] = -1; }
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_rowext_kernel(const float* __restrict__ heat, size_t total, int h, int w, float low_text,
+                                                         const int* __restrict__ label, const int* __restrict__ slot,
+                                                         const CclOut* __restrict__ comps, int* rowext, int cap_comps, int cap_rows) {
+    const int hw = h * w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = label[i];
+        if (r < 0) continue;
+        if (!(heat[i * 2] > low_text)) continue;   // link-only pixels are removed from the segmentation map
+        const int s = slot[r];
+        if (s < 0) continue;
+        const int img = (int)(i / hw);
+        const CclOut c = comps[(size_t)img * cap_comps + s];
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        int* re = rowext + ((size_t)img * cap_rows + c.row_off + (y - c.top)) * 2;
+        atomicMin(re, x);
+        atomicMax(re + 1, x);
+    }
+}
+
+hipError_t launch_ccl(const float* heat, int N, int h, int w, float low_text, float link_thr, double text_thr, int* label, int* stat,
+                      int* slot, CclOut* comps, int* rowext, int* counters, int cap_comps, int cap_rows, hipStream_t s) {
+    const size_t total = (size_t)N * h * w;
+    if (total == 0) return hipSuccess;
+    if (total > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * N, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, heat, total, low_text, link_thr, label, stat, slot);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid), dim3(256), 0, s, total, h, w, label);
+    hipLaunchKernelGGL(ccl_stats_kernel, dim3(grid), dim3(256), 0, s, heat, total, h, w, label, stat);
+    hipLaunchKernelGGL(ccl_accept_kernel, dim3(grid), dim3(256), 0, s, total, h * w, text_thr, label, stat, slot, comps, rowext, counters,
+                       cap_comps, cap_rows);
+    hipLaunchKernelGGL(ccl_rowext_kernel, dim3(grid), dim3(256), 0, s, heat, total, h, w, low_text, label, slot, comps, rowext, cap_comps,
+                       cap_rows);
+    return hipGetLastError();
+}

@@ -1,0 +1,52 @@
+// Shared device/host helpers for libbbocr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// round-to-nearest-even f32 -> bf16 bits (host); device code uses the hardware cvt via __bf16 casts
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32_host(uint16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN preserved)
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so
+// neighbouring tiles (same activation patch / same weight panel) share one L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            throw std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+        }                                                                                  \
+    } while (0)

@@ -1,0 +1,307 @@
+// Recogniser-side kernels other than the MFMA convs and the LSTM: box crops (cv2 bilinear / warpPerspective / PIL
+// bicubic, all integer-exact restatements), contrast histogram, normalise+pad, CRNN conv0, 3-row mean.
+// Upstream stages restated: easyocr/utils.py::{get_image_list,four_point_transform,compute_ratio_and_resize},
+// easyocr/recognition.py::{AlignCollate,NormalizePAD,adjust_contrast_grey}, model/modules.py::VGG_FeatureExtractor
+// (first conv) and vgg_model.py::Model (AdaptiveAvgPool2d((None,1))); reference call site
+// pipeline_demo/extractor/enhanced_extractor.py:520.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ warpPerspective
+// cv2.warpPerspective(gray, M, (ww, wh)), INTER_LINEAR, BORDER_CONSTANT 0: coordinates rounded to 1/32 px (cvRound of a
+// double), weights (32-ax)(32-ay)*32 etc. (exact 15-bit table entries), result (sum + 2^14) >> 15.
+__global__ void __launch_bounds__(256) crop_warp_kernel(const uint8_t* __restrict__ gray, int H, int W, const CropDesc* __restrict__ descs,
+                                                        int first, uint8_t* __restrict__ wscratch) {
+    const CropDesc d = descs[first + blockIdx.y];
+    if (!d.warp) return;
+    const uint8_t* src = gray + (size_t)d.img * H * W;
+    uint8_t* dst = wscratch + d.warp_off;
+    const int total = d.sw * d.sh;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int x = i % d.sw, y = i / d.sw;
+        const double X0 = d.Minv[0] * (double)x + (d.Minv[1] * (double)y + d.Minv[2]);
+        const double Y0 = d.Minv[3] * (double)x + (d.Minv[4] * (double)y + d.Minv[5]);
+        const double W0 = d.Minv[6] * (double)x + (d.Minv[7] * (double)y + d.Minv[8]);
+        const double Wi = W0 != 0.0 ? 32.0 / W0 : 0.0;
+        double fX = X0 * Wi, fY = Y0 * Wi;
+        fX = fX < -2147483648.0 ? -2147483648.0 : (fX > 2147483647.0 ? 2147483647.0 : fX);
+        fY = fY < -2147483648.0 ? -2147483648.0 : (fY > 2147483647.0 ? 2147483647.0 : fY);
+        const long long X = (long long)rint(fX), Y = (long long)rint(fY);
+        long long sxl = X >> 5, syl = Y >> 5;
+        sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+        syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+        const int sx = (int)sxl, sy = (int)syl;
+        const int ax = (int)(X & 31), ay = (int)(Y & 31);
+        auto tap = [&](int yy, int xx) -> int {
+            return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (int)src[(size_t)yy * W + xx] : 0;
+        };
+        const int acc = tap(sy, sx) * ((32 - ax) * (32 - ay) * 32) + tap(sy, sx + 1) * (ax * (32 - ay) * 32) +
+                        tap(sy + 1, sx) * ((32 - ax) * ay * 32) + tap(sy + 1, sx + 1) * (ax * ay * 32);
+        int v = (acc + (1 << 14)) >> 15;
+        dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cv2 bilinear crop
+__device__ __forceinline__ void cv_lin_coef_d(int d, int ssize, double scale, int& s0, int& s1, int& a0, int& a1) {
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+    a0 = __float2int_rn((1.f - fx) * 2048.f);
+    a1 = __float2int_rn(fx * 2048.f);
+    s0 = sx;
+    s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
+}
+
+__global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restrict__ gray, int H, int W, const CropDesc* __restrict__ descs,
+                                                          int first, const uint8_t* __restrict__ wscratch, uint8_t* __restrict__ scratch) {
+    const CropDesc d = descs[first + blockIdx.y];
+    const uint8_t* src;
+    int stride;
+    if (d.warp) { src = wscratch + d.warp_off; stride = d.sw; }
+    else { src = gray + (size_t)d.img * H * W + (size_t)d.sy0 * W + d.sx0; stride = W; }
+    uint8_t* dst = scratch + d.a_off;
+    const int sw = d.sw, sh = d.sh, dw = d.rw, dh = d.rh;
+    const bool same = (dw == sw && dh == sh), area2 = (sw == 2 * dw && sh == 2 * dh);
+    const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
+    const int total = dw * dh;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int dx = i % dw, dy = i / dw;
+        int v;
+        if (same) {
+            v = src[(size_t)dy * stride + dx];
+        } else if (area2) {
+            v = (src[(size_t)(2 * dy) * stride + 2 * dx] + src[(size_t)(2 * dy) * stride + 2 * dx + 1] +
+                 src[(size_t)(2 * dy + 1) * stride + 2 * dx] + src[(size_t)(2 * dy + 1) * stride + 2 * dx + 1] + 2) >> 2;
+        } else {
+            int x0, x1, a0, a1, y0, y1, b0, b1;
+            cv_lin_coef_d(dx, sw, scale_x, x0, x1, a0, a1);
+            cv_lin_coef_d(dy, sh, scale_y, y0, y1, b0, b1);
+            const int r0 = src[(size_t)y0 * stride + x0] * a0 + src[(size_t)y0 * stride + x1] * a1;
+            const int r1 = src[(size_t)y1 * stride + x0] * a0 + src[(size_t)y1 * stride + x1] * a1;
+            v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        dst[i] = (uint8_t)v;
+    }
+}
+
+// 256-bin histogram of each stage-A crop (for np.percentile in adjust_contrast_grey; finished on the host in double)
+__global__ void __launch_bounds__(256) crop_hist_kernel(const uint8_t* __restrict__ scratch, const CropDesc* __restrict__ descs, int first,
+                                                        unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[256];
+    const CropDesc d = descs[first + blockIdx.x];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t* p = scratch + d.a_off;
+    const int total = d.rw * d.rh;
+    for (int i = threadIdx.x; i < total; i += 256) atomicAdd(&h[p[i]], 1u);
+    __syncthreads();
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------ PIL bicubic (8 bpc)
+#define PIL_PREC 22
+#define PIL_MAXK 132
+__device__ __forceinline__ double pil_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+// coefficients of output sample xx (Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc); returns tap count
+__device__ int pil_coeffs(int in_size, int out_size, int xx, int& xmin, int* kk) {
+    double scale = (double)in_size / (double)out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 2.0 * filterscale;
+    const double center = ((double)xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int x0 = (int)(center - support + 0.5);
+    if (x0 < 0) x0 = 0;
+    int x1 = (int)(center + support + 0.5);
+    if (x1 > in_size) x1 = in_size;
+    int n = x1 - x0;
+    if (n > PIL_MAXK) n = PIL_MAXK;
+    double ww = 0.0;
+    for (int x = 0; x < n; ++x) ww += pil_bicubic(((double)(x + x0) - center + 0.5) * ss);
+    for (int x = 0; x < n; ++x) {
+        double w = pil_bicubic(((double)(x + x0) - center + 0.5) * ss);
+        if (ww != 0.0) w = w / ww;
+        kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << PIL_PREC)) : (int)(0.5 + w * (double)(1 << PIL_PREC));
+    }
+    xmin = x0;
+    return n;
+}
+__device__ __forceinline__ int pil_clip8(long long v) {
+    const long long r = v >> PIL_PREC;
+    return r < 0 ? 0 : (r > 255 ? 255 : (int)r);
+}
+
+// stage B0 (tall boxes only): horizontal PIL pass  [rh][rw] -> [rh][fw] uint8 into hscratch
+__global__ void __launch_bounds__(256) crop_pil_h_kernel(const CropDesc* __restrict__ descs, int first, const uint8_t* __restrict__ scratch,
+                                                         const uint8_t* __restrict__ luts, uint8_t* __restrict__ hscratch) {
+    const CropDesc d = descs[first + blockIdx.y];
+    if (d.fw == d.rw && d.rh == 64) return;
+    const uint8_t* src = scratch + d.a_off;
+    const uint8_t* lut = d.lut_off >= 0 ? luts + d.lut_off : nullptr;
+    uint8_t* dst = hscratch + d.a_off;    // same offsets: fw <= rw so the region fits
+    const int total = d.rh * d.fw;
+    int kk[PIL_MAXK];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int xx = i % d.fw, y = i / d.fw;
+        int v;
+        if (d.fw == d.rw) {
+            v = src[(size_t)y * d.rw + xx];
+            if (lut) v = lut[v];
+        } else {
+            int xmin;
+            const int n = pil_coeffs(d.rw, d.fw, xx, xmin, kk);
+            long long acc = 1LL << (PIL_PREC - 1);
+            for (int k = 0; k < n; ++k) {
+                int p = src[(size_t)y * d.rw + xmin + k];
+                if (lut) p = lut[p];
+                acc += (long long)p * kk[k];
+            }
+            v = pil_clip8(acc);
+        }
+        dst[i] = (uint8_t)v;
+    }
+}
+
+// stage B: (vertical PIL pass for tall boxes |  plain copy) + contrast LUT + ToTensor/normalise + right edge-replicate pad
+//   out bf16 [slot][64][imgW]
+__global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restrict__ descs, int first, const uint8_t* __restrict__ scratch,
+                                                         const uint8_t* __restrict__ hscratch, const uint8_t* __restrict__ luts,
+                                                         uint16_t* __restrict__ out, int imgW) {
+    const CropDesc d = descs[first + blockIdx.y];
+    const bool tall = !(d.fw == d.rw && d.rh == 64);
+    const uint8_t* src = (tall ? hscratch : scratch) + d.a_off;
+    const uint8_t* lut = (!tall && d.lut_off >= 0) ? luts + d.lut_off : nullptr;
+    uint16_t* dst = out + (size_t)d.slot * 64 * imgW;
+    const int total = 64 * imgW;
+    int kk[PIL_MAXK];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int x = i % imgW, y = i / imgW;
+        const int xs = x < d.fw ? x : d.fw - 1;
+        int v;
+        if (!tall) {
+            v = src[(size_t)y * d.rw + xs];
+            if (lut) v = lut[v];
+        } else if (d.rh == 64) {
+            v = src[(size_t)y * d.fw + xs];
+        } else {
+            int ymin;
+            const int n = pil_coeffs(d.rh, 64, y, ymin, kk);
+            long long acc = 1LL << (PIL_PREC - 1);
+            for (int k = 0; k < n; ++k) acc += (long long)src[(size_t)(ymin + k) * d.fw + xs] * kk[k];
+            v = pil_clip8(acc);
+        }
+        const float t = ((float)v / 255.0f - 0.5f) / 0.5f;
+        dst[i] = f32_to_bf16_bits(t);
+    }
+}
+
+hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
+                        int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
+                        int stage_mask, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    if (stage_mask & 1) {
+        if (any_warp) hipLaunchKernelGGL(crop_warp_kernel, dim3(16, count), dim3(256), 0, s, gray, H, W, descs_dev, first, wscratch);
+        hipLaunchKernelGGL(crop_resize_kernel, dim3(16, count), dim3(256), 0, s, gray, H, W, descs_dev, first, wscratch, scratch);
+    }
+    if (stage_mask & 2) {
+        if (any_tall) hipLaunchKernelGGL(crop_pil_h_kernel, dim3(8, count), dim3(256), 0, s, descs_dev, first, scratch, luts, hscratch);
+        hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, imgW);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, int first, int count, unsigned int* hist, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(crop_hist_kernel, dim3(count), dim3(256), 0, s, scratch, descs_dev, first, hist);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ CRNN conv0 + pool
+// FeatureExtraction.ConvNet.0 (1->32, 3x3, pad 1) + ReLU + MaxPool2d(2,2): one pooled pixel x 32 channels per thread.
+__global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ b, uint16_t* __restrict__ out, int n, int W) {
+    const int OW = W / 2, OH = 32;
+    const size_t total = (size_t)n * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW);
+        const size_t r = i / OW;
+        const int oy = (int)(r % OH);
+        const int img = (int)(r / OH);
+        const uint16_t* p = in + (size_t)img * 64 * W;
+        float v[4][4];   // 4x4 input window around the 2x2 conv outputs
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
+                v[dy][dx] = (iy >= 0 && iy < 64 && ix >= 0 && ix < W) ? bf16_bits_to_f32(p[(size_t)iy * W + ix]) : 0.f;
+            }
+        uint16_t* op = out + i * 32;
+#pragma unroll 4
+        for (int c = 0; c < 32; c += 2) {
+            float m[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const float* wc = w + (c + cc) * 9;
+                float best = 0.f;   // ReLU floor
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        float a = b[c + cc];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a = fmaf(wc[ky * 3 + kx], v[py + ky][px + kx], a);
+                        best = fmaxf(best, a);
+                    }
+                m[cc] = best;
+            }
+            *(unsigned int*)(op + c) = pack_bf16x2(m[0], m[1]);
+        }
+    }
+}
+
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w, const float* b, uint16_t* out, int n, int W, hipStream_t s) {
+    const size_t total = (size_t)n * 32 * (W / 2);
+    if (total == 0) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(crnn_conv0_kernel, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ mean over 3 rows
+__global__ void __launch_bounds__(256) rowmean3_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int T, int C8) {
+    const size_t total = (size_t)n * T * C8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t per = (size_t)T * C8;
+        const size_t img = i / per, rem = i - img * per;
+        const uint16_t* p = in + (img * 3 * per + rem) * 8;
+        const u32x4 a = *(const u32x4*)(p), bq = *(const u32x4*)(p + per * 8), c = *(const u32x4*)(p + 2 * per * 8);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = (__uint_as_float(a[j] << 16) + __uint_as_float(bq[j] << 16) + __uint_as_float(c[j] << 16)) / 3.0f;
+            const float hi = (__uint_as_float(a[j] & 0xffff0000u) + __uint_as_float(bq[j] & 0xffff0000u) + __uint_as_float(c[j] & 0xffff0000u)) / 3.0f;
+            o[j] = pack_bf16x2(lo, hi);
+        }
+        *(u32x4*)(out + i * 8) = o;
+    }
+}
+
+hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s) {
+    const size_t total = (size_t)n * T * (C / 8);
+    if (total == 0) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(rowmean3_kernel, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
+    return hipGetLastError();
+}

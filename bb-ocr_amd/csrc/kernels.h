@@ -1,0 +1,87 @@
+// Internal launch interface between the C-ABI layer (api.cpp) and the HIP kernels.  Not public.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ------------------------------------------------------------------ implicit-GEMM convolution (conv_mfma.hip)
+struct ConvArgs {
+    const uint16_t* in0;   // bf16 NHWC source 0
+    const uint16_t* in1;   // bf16 NHWC source 1 (virtual channel concat after source 0) or null
+    const uint16_t* wpk;   // packed bf16 weights, see pack_conv_weights()
+    const float* bias;     // fp32 [Cout_pad] (BN folded), natural cout order
+    void* out;             // bf16 or fp32 NHWC
+    int C0, C1;            // channels taken from each source (multiples of 32)
+    int in0_cs, in1_cs;    // pixel strides (elements) of the sources
+    int N, H, W, OH, OW;
+    int KH, KW, pad_h, pad_w, dil;
+    int TH, TW, tiles_x, tiles_y, ntiles_n;
+    int PH, PW, NP;        // activation patch (TH+(KH-1)dil) x (TW+(KW-1)dil), NP = roundup16(PH*PW)
+    int relu_in0, relu_in1, relu_out, out_f32;
+    int out_cs, cout_store;  // output pixel stride (elements), couts actually stored (multiple of 16)
+    int nchunks, ntaps;
+};
+
+struct ConvPlan {      // host-side description of one packed conv layer
+    int Cin = 0, Cout = 0;     // logical sizes
+    int Cin_pad = 0, Cout_pad = 0;
+    int KH = 1, KW = 1, pad_h = 0, pad_w = 0, dil = 1;
+    int BN = 64;       // cout tile of the launch config chosen for this layer (64/128/256)
+    uint16_t* d_w = nullptr;   // device packed weights
+    float* d_b = nullptr;      // device bias [Cout_pad]
+};
+
+size_t conv_packed_elems(const ConvPlan& p);
+// w: fp32 [Cout][Cin][KH][KW] already BN-folded; out: bf16 bits, layout [ntile][chunk][tap][frag][lane][8]
+void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out);
+hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);
+
+// ------------------------------------------------------------------ detector front/back (craft_misc.hip)
+hipError_t launch_conv1_1(const uint8_t* rgb, int N, int Himg, int Wimg, int H32, int W32, const uint16_t* wpk, const float* bias,
+                          uint16_t* out, hipStream_t s);
+void pack_conv1_1_weights(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/);
+hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int relu_in, hipStream_t s);
+hipError_t launch_upsample2x(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_cls_tail(const uint16_t* in, const float* w1, const float* b1, const float* w2, const float* b2, float* out, size_t npix,
+                           hipStream_t s);
+hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
+hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw, hipStream_t s);
+
+// ------------------------------------------------------------------ box extraction (ccl.hip)
+struct CclOut {        // per accepted component, device-written, host-sorted by root
+    int root, left, top, right, bottom, area, row_off, pad;
+};
+// label/slot: [N*h*w]; stat: [N*h*w][6]; comps: [N][cap_comps]; rowext: [N][cap_rows][2]; counters: [N][4] = ncomps, nrows, overflow
+hipError_t launch_ccl(const float* heat, int N, int h, int w, float low_text, float link_thr, double text_thr, int* label, int* stat,
+                      int* slot, CclOut* comps, int* rowext, int* counters, int cap_comps, int cap_rows, hipStream_t s);
+
+// ------------------------------------------------------------------ recogniser (crnn_misc.hip, lstm.hip, ctc.hip)
+struct CropDesc {      // one recogniser input, filled on the host
+    int img;           // page index in the batch
+    int sx0, sy0, sw, sh;   // source rectangle: in the gray page, or (0,0,ww,wh) of the warped crop when warp != 0
+    int rw, rh;        // cv2.resize target; rh == 64 unless the box is taller than wide (then rw == 64)
+    int fw;            // content width after AlignCollate (<= imgW)
+    int imgW;          // padded width (bucket)
+    int slot;          // row inside the bucket tensor
+    int warp;          // 1: four_point_transform crop, uses Minv
+    int warp_off;      // byte offset of the warped crop in the warp scratch
+    int a_off;         // byte offset of the stage-A (cv2-resized) crop in the crop scratch
+    int lut_off;       // >= 0: contrast LUT (256 bytes) offset, -1: none
+    int pad_;
+    double Minv[9];    // dst -> src homography (already inverted)
+};
+// stage_mask bit0: gather (warp) + cv2 resize into scratch; bit1: (PIL bicubic) + LUT + normalise + pad into out_bucket
+hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
+                        int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
+                        int stage_mask, hipStream_t s);
+hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, int first, int count, unsigned int* hist, hipStream_t s);
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, hipStream_t s);
+hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s);
+// BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
+hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, int n, int T, hipStream_t s);
+void pack_lstm_whh(const float* whh_fwd /*[1024][256]*/, const float* whh_bwd, uint16_t* out);
+size_t lstm_whh_packed_elems();
+int lstm_xproj_channel(int dir, int gate, int unit);
+struct CtcOut { int len; int cnt; float prod; int pad; };
+hipError_t launch_ctc(const float* logits, int n, int T, int C, int cs, int* idx_tmp, float* pmax_tmp, int* out_idx, CtcOut* out,
+                      hipStream_t s);

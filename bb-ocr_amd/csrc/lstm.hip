@@ -1,0 +1,144 @@
+// Bidirectional LSTM recurrence (hidden 256) as a persistent per-sequence-tile kernel on MFMA.
+//
+// Restates torch.nn.LSTM(256, 256, bidirectional=True, batch_first=True) as used by
+// easyocr/model/modules.py::BidirectionalLSTM (recogniser SequenceModeling.{0,1}.rnn), reached from
+// reader.readtext (pipeline_demo/extractor/enhanced_extractor.py:520).  The input projection x W_ih^T + b_ih + b_hh
+// is ONE batched GEMM done by conv_mfma (1x1 conv, permuted output channels); this kernel does the T sequential
+// steps.  One workgroup = 16 sequences x one direction, 4 waves; wave w owns hidden units [64w, 64w+64) and all four
+// of their gates, so the gate non-linearity is lane-local:
+//   D[seq][gate col] = h_{t-1}[seq][k] * W_hh^T[k][gate col]   (A = h from LDS, B = W_hh streamed from L2 in fragment order)
+//   fragment (u16, gate): lane l holds unit 64w+16*u16+(l&15) for sequences 4(l>>4)+r.
+// c stays in fp32 registers for all T steps; h crosses LDS as bf16 (it is the next step's A operand).
+#include "common.h"
+#include "kernels.h"
+
+size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
+
+// out layout: [dir][wave 4][kk 8][u16 4][gate 4][lane 64][8]
+void pack_lstm_whh(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
+    size_t o = 0;
+    for (int d = 0; d < 2; ++d) {
+        const float* W = d ? whh_bwd : whh_fwd;
+        for (int w = 0; w < 4; ++w)
+            for (int kk = 0; kk < 8; ++kk)
+                for (int u16 = 0; u16 < 4; ++u16)
+                    for (int gate = 0; gate < 4; ++gate)
+                        for (int l = 0; l < 64; ++l) {
+                            const int unit = w * 64 + u16 * 16 + (l & 15);
+                            const int row = gate * 256 + unit;
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = kk * 32 + 8 * (l >> 4) + j;
+                                out[o++] = f32_to_bf16_host(W[(size_t)row * 256 + k]);
+                            }
+                        }
+    }
+}
+
+// Channel permutation of the input projection so that one lane's 16 gate pre-activations of one sequence are 32
+// contiguous bytes: perm(dir, gate, unit) = dir*1024 + ((unit>>6)*16 + (unit&15))*16 + ((unit>>4)&3)*4 + gate.
+int lstm_xproj_channel(int dir, int gate, int unit) {
+    return dir * 1024 + (((unit >> 6) * 16 + (unit & 15)) * 16) + ((unit >> 4) & 3) * 4 + gate;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+
+__global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
+                                                      uint16_t* __restrict__ out, int n, int T) {
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][32 * 16 * 16];   // [kgroup 32][seq 16] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * 16;
+    const int g = lane >> 4, u = lane & 15;
+
+    for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 256) ((u32x4*)hbuf)[i] = (u32x4){0u, 0u, 0u, 0u};
+    float c[4][4];   // [u16][r]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
+    const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
+    // xproj element offset of this lane's 16 contiguous channels
+    const int xch = dir * 1024 + (wave * 16 + u) * 16;
+    // coalesced h write-back: thread -> (seq, 16-B chunk of the 256 units)
+    const int wb_seq = tid >> 4, wb_kg0 = (tid & 15) * 2;
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        // gate pre-activations from the input projection (bf16): 4 sequences x 32 B per lane
+        u32x4 xq[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = seq0 + g * 4 + r;
+            if (s < n) {
+                const uint16_t* xp = xproj + ((size_t)s * T + t) * 2048 + xch;
+                xq[r][0] = *(const u32x4*)(xp);
+                xq[r][1] = *(const u32x4*)(xp + 8);
+            } else {
+                xq[r][0] = (u32x4){0u, 0u, 0u, 0u};
+                xq[r][1] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+        f32x4 acc[4][4];   // [u16][gate]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* hb = hbuf[cur];
+        // W_hh is step-invariant; hiding the pointer keeps hipcc from hoisting 128 fragment loads out of the time loop
+        // (512 VGPRs + spills).  The fragments stream from L2 every step instead.
+        const bf16x8* wv = wv0;
+        asm volatile("" : "+v"(wv));
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const bf16x8 af = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 bfr = wv[(size_t)((kk * 4 + a) * 4 + q) * 64];
+                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[a][q], 0, 0, 0);
+                }
+        }
+        unsigned char* hn = hbuf[cur ^ 1];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int unit = wave * 64 + a * 16 + u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // lane's 16 xproj values for sequence r: index a*4 + gate
+                const unsigned int w0 = xq[r][a >> 1][(a & 1) * 2], w1 = xq[r][a >> 1][(a & 1) * 2 + 1];
+                const float gi = acc[a][0][r] + __uint_as_float(w0 << 16);
+                const float gf = acc[a][1][r] + __uint_as_float(w0 & 0xffff0000u);
+                const float gg = acc[a][2][r] + __uint_as_float(w1 << 16);
+                const float go = acc[a][3][r] + __uint_as_float(w1 & 0xffff0000u);
+                const float cn = sigmoid_f(gf) * c[a][r] + sigmoid_f(gi) * tanh_f(gg);
+                c[a][r] = cn;
+                const float hv = sigmoid_f(go) * tanh_f(cn);
+                *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
+            }
+        }
+        __syncthreads();
+        // h_t -> out[seq][t][dir*256 + unit], 32 B per thread
+        {
+            const int s = seq0 + wb_seq;
+            if (s < n) {
+                const u32x4 h0 = *(const u32x4*)(hn + ((wb_kg0) * 16 + wb_seq) * 16);
+                const u32x4 h1 = *(const u32x4*)(hn + ((wb_kg0 + 1) * 16 + wb_seq) * 16);
+                uint16_t* op = out + ((size_t)s * T + t) * 512 + dir * 256 + wb_kg0 * 8;
+                *(u32x4*)(op) = h0;
+                *(u32x4*)(op + 8) = h1;
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, int n, int T, hipStream_t s) {
+    if (n <= 0 || T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lstm_kernel, dim3((n + 15) / 16, 2), dim3(256), 0, s, xproj, whh_pk, out, n, T);
+    return hipGetLastError();
+}

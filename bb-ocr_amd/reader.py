@@ -1,0 +1,309 @@
+"""``Reader``: the host-side mirror of ``easyocr.Reader`` for the one path BB-OCR uses.
+
+Reference call sites this class stands in for (same names, argument meaning, return
+shape and error behaviour):
+  * ``easyocr.Reader(["en"], gpu=use_gpu)``        pipeline_demo/extractor/enhanced_extractor.py:153
+  * ``reader.readtext(path, paragraph=False, batch_size=1, workers=0)``          ...:520
+    consumed as ``" ".join(result[1] for result in results)`` (:521), any exception is
+    caught by the caller and turns into empty text (:529-531)
+  * ``for (bbox, text, prob) in reader.readtext(path)``   pipeline_components/img_to_json/
+    ocr_testing/ocr_engines/test_easyocr.py:23,50
+Upstream semantics followed: easyocr==1.7.2 ``easyocr/easyocr.py::Reader.{__init__,detect,
+recognize,readtext,readtext_batched}``.
+
+Everything numeric happens in libbbocr.so (HIP kernels) through the C ABI in
+``include/bbocr.h``; torch is used only to hold device memory.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import os
+import threading
+
+import numpy as np
+
+from . import _lib
+from . import weights as _weights
+
+# english_g2 character list (easyocr/config.py); index 0 of the class axis is the CTC blank
+_SYMBOLS = "0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~ €"
+CHARSET = _SYMBOLS + "ABCDEFGHIJKLMNOPQRSTUVWXYZ" + "abcdefghijklmnopqrstuvwxyz"
+CHARACTER = ["[blank]"] + list(CHARSET)
+
+_DET_KW = ("min_size", "text_threshold", "low_text", "link_threshold", "canvas_size", "mag_ratio", "slope_ths", "ycenter_ths",
+           "height_ths", "width_ths", "add_margin")
+
+
+def _gray_bgr2gray(a: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(a, COLOR_BGR2GRAY) fixed point on the channels as given."""
+    a = a.astype(np.int32)
+    return ((a[..., 2] * 4899 + a[..., 1] * 9617 + a[..., 0] * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def reformat_input(image):
+    """easyocr/utils.py::reformat_input -> (RGB uint8 HWC, gray uint8 HW); decode is host work (PIL)."""
+    from PIL import Image
+
+    if isinstance(image, (str, os.PathLike)):
+        pil = Image.open(os.path.expanduser(str(image)))
+        return np.ascontiguousarray(pil.convert("RGB")), np.ascontiguousarray(pil.convert("L"))
+    if isinstance(image, (bytes, bytearray)):
+        pil = Image.open(io.BytesIO(bytes(image)))
+        img = np.ascontiguousarray(pil.convert("RGB"))
+        return img, _gray_bgr2gray(img)
+    if isinstance(image, np.ndarray):
+        if image.dtype != np.uint8:
+            raise ValueError("Invalid input type. numpy input must be uint8")
+        if image.ndim == 2:
+            return np.ascontiguousarray(np.repeat(image[:, :, None], 3, axis=2)), np.ascontiguousarray(image)
+        if image.ndim == 3 and image.shape[2] == 1:
+            g = np.ascontiguousarray(image[:, :, 0])
+            return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)), g
+        if image.ndim == 3 and image.shape[2] == 3:
+            return np.ascontiguousarray(image), _gray_bgr2gray(image)
+        if image.ndim == 3 and image.shape[2] == 4:
+            img = np.ascontiguousarray(image[:, :, :3][:, :, ::-1])
+            return img, _gray_bgr2gray(img)
+    elif hasattr(image, "convert"):
+        arr = np.asarray(image.convert("RGB"))
+        return np.ascontiguousarray(arr[:, :, ::-1]), _gray_bgr2gray(arr)
+    raise ValueError("Invalid input type. Supporting format = string(file path or url), bytes, numpy array")
+
+
+class Reader:
+    """Drop-in for ``easyocr.Reader`` (English ``english_g2`` recogniser + CRAFT detector) on one MI355X."""
+
+    def __init__(self, lang_list, gpu=True, model_storage_directory=None, user_network_directory=None,
+                 detect_network="craft", recog_network="standard", download_enabled=True, detector=True, recognizer=True,
+                 verbose=True, quantize=True, cudnn_benchmark=False, weights=None, device_index=None, det_sub_batch=0,
+                 rec_max_cols=0, **_ignored):
+        import torch
+
+        if list(lang_list) != ["en"]:
+            raise ValueError(f"{lang_list} is not supported: this backend ships the English (english_g2) model only")
+        if detect_network != "craft":
+            raise ValueError("only detect_network='craft' is implemented")
+        if not torch.cuda.is_available():
+            raise RuntimeError("bb_ocr_amd.Reader needs a HIP device (MI355X); there is no CPU path")
+        self._torch = torch
+        self.device_index = torch.cuda.current_device() if device_index is None else int(device_index)
+        self.device = f"cuda:{self.device_index}"
+        self._lib = _lib.load()
+        self._lock = threading.Lock()
+        cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols))
+        h = C.c_void_p()
+        rc = self._lib.bbocr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"bbocr_create failed with status {rc}")
+        self._h = h
+        self.character = CHARACTER
+        self.lang_char = list(CHARSET)
+        craft_state, crnn_state = self._resolve_weights(weights, model_storage_directory)
+        if detector:
+            self._load(0, craft_state)
+        if recognizer:
+            self._load(1, crnn_state)
+
+    # -- weights -------------------------------------------------------------------
+    @staticmethod
+    def _resolve_weights(weights, model_storage_directory):
+        if isinstance(weights, tuple):
+            return weights
+        if weights == "synthetic" or os.environ.get("BBOCR_SYNTHETIC_WEIGHTS", "") == "1":
+            return _weights.designed_craft_state(0), _weights.synthetic_crnn_state(0)
+        directory = model_storage_directory or os.environ.get("BBOCR_WEIGHTS_DIR") or os.path.expanduser("~/.EasyOCR/model")
+        return _weights.load_checkpoint_dir(directory)
+
+    def _load(self, which, state):
+        arr, keep = _weights.to_descs(state)
+        self._check(self._lib.bbocr_load_weights(self._h, which, arr, len(arr)))
+        del keep
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.bbocr_last_error(self._h)
+            raise RuntimeError(f"libbbocr status {rc}: {msg.decode(errors='replace') if msg else ''}")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bbocr_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------
+    def _params(self, kw):
+        p = _lib.bbocr_params()
+        self._lib.bbocr_default_params(C.byref(p))
+        for k in _DET_KW + ("contrast_ths", "adjust_contrast"):
+            if k in kw and kw[k] is not None:
+                setattr(p, k, kw[k])
+        return p
+
+    def _to_dev(self, arr):
+        t = self._torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        self._torch.cuda.current_stream(self.device_index).synchronize()
+        return t
+
+    def _collect(self, res_p, detail=1):
+        r = res_p.contents
+        out = []
+        try:
+            for b in range(r.n_images):
+                page = []
+                for i in range(r.box_off[b], r.box_off[b + 1]):
+                    q = [r.quads[i * 8 + k] for k in range(8)]
+                    if r.is_free[i]:
+                        box = [[q[0], q[1]], [q[2], q[3]], [q[4], q[5]], [q[6], q[7]]]
+                    else:
+                        box = [[int(q[0]), int(q[1])], [int(q[2]), int(q[3])], [int(q[4]), int(q[5])], [int(q[6]), int(q[7])]]
+                    text = "".join(CHARACTER[r.text_idx[k]] for k in range(r.text_off[i], r.text_off[i + 1]))
+                    page.append((box, text, float(r.conf[i])))
+                out.append(page)
+        finally:
+            self._lib.bbocr_free_result(res_p)
+        if detail == 0:
+            return [[item[1] for item in page] for page in out]
+        return out
+
+    def stage_times(self):
+        ms = (C.c_float * 8)()
+        self._check(self._lib.bbocr_stage_times(self._h, ms, 8))
+        keys = ("detector_net", "ccl_device", "box_geometry_host", "crops", "recognizer_net", "ctc", "contrast_retry", "total")
+        return dict(zip(keys, [float(v) for v in ms]))
+
+    # -- easyocr surface ---------------------------------------------------------------
+    def readtext_device(self, rgb_dev, gray_dev=None, **kw):
+        """Batch entry for pages already resident in HBM: uint8 torch tensors [B,H,W,3] (+ optional [B,H,W])."""
+        B, H, W, _ = rgb_dev.shape
+        p = self._params(kw)
+        res = C.POINTER(_lib.bbocr_result)()
+        gp = C.c_void_p(gray_dev.data_ptr()) if gray_dev is not None else C.c_void_p(None)
+        self._check(self._lib.bbocr_readtext_batch(self._h, C.c_void_p(rgb_dev.data_ptr()), gp, B, H, W, C.byref(p), C.byref(res)))
+        return self._collect(res, kw.get("detail", 1))
+
+    def readtext(self, image, decoder="greedy", beamWidth=5, batch_size=1, workers=0, allowlist=None, blocklist=None, detail=1,
+                 rotation_info=None, paragraph=False, min_size=20, contrast_ths=0.1, adjust_contrast=0.5, filter_ths=0.003,
+                 text_threshold=0.7, low_text=0.4, link_threshold=0.4, canvas_size=2560, mag_ratio=1.0, slope_ths=0.1, ycenter_ths=0.5,
+                 height_ths=0.5, width_ths=0.5, y_ths=0.5, x_ths=1.0, add_margin=0.1, threshold=0.2, bbox_min_score=0.2, bbox_min_size=3,
+                 max_candidates=0, output_format="standard"):
+        """``image -> [(bbox, text, confidence)]`` exactly as ``easyocr.Reader.readtext`` shapes it."""
+        self._unsupported(decoder, allowlist, blocklist, rotation_info, paragraph, output_format)
+        img, grey = reformat_input(image)
+        kw = dict(min_size=min_size, contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, text_threshold=text_threshold,
+                  low_text=low_text, link_threshold=link_threshold, canvas_size=canvas_size, mag_ratio=mag_ratio, slope_ths=slope_ths,
+                  ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail)
+        return self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]), **kw)[0]
+
+    def readtext_batched(self, image, n_width=None, n_height=None, **kw):
+        """List (or 4-D array) of pages -> list of per-page results.  Equal-size pages share one device batch."""
+        self._unsupported(kw.pop("decoder", "greedy"), kw.pop("allowlist", None), kw.pop("blocklist", None), kw.pop("rotation_info", None),
+                          kw.pop("paragraph", False), kw.pop("output_format", "standard"))
+        for k in ("beamWidth", "batch_size", "workers", "filter_ths", "y_ths", "x_ths", "threshold", "bbox_min_score", "bbox_min_size",
+                  "max_candidates"):
+            kw.pop(k, None)
+        pages = [reformat_input(im) for im in image]
+        if n_width is not None and n_height is not None:
+            from PIL import Image
+
+            pages = [(np.asarray(Image.fromarray(a).resize((n_width, n_height), Image.BILINEAR)),
+                      np.asarray(Image.fromarray(g).resize((n_width, n_height), Image.BILINEAR))) for a, g in pages]
+        out = [None] * len(pages)
+        by_shape = {}
+        for i, (a, g) in enumerate(pages):
+            by_shape.setdefault(a.shape, []).append(i)
+        for _, idxs in by_shape.items():
+            rgb = self._to_dev(np.stack([pages[i][0] for i in idxs]))
+            gray = self._to_dev(np.stack([pages[i][1] for i in idxs]))
+            for i, r in zip(idxs, self.readtext_device(rgb, gray, **kw)):
+                out[i] = r
+        return out
+
+    def detect(self, img, min_size=20, text_threshold=0.7, low_text=0.4, link_threshold=0.4, canvas_size=2560, mag_ratio=1.0,
+               slope_ths=0.1, ycenter_ths=0.5, height_ths=0.5, width_ths=0.5, add_margin=0.1, reformat=True, **_ignored):
+        """``Reader.detect`` -> (horizontal_list_agg, free_list_agg) for one page."""
+        if reformat:
+            img, _ = reformat_input(img)
+        kw = dict(min_size=min_size, text_threshold=text_threshold, low_text=low_text, link_threshold=link_threshold,
+                  canvas_size=canvas_size, mag_ratio=mag_ratio, slope_ths=slope_ths, ycenter_ths=ycenter_ths, height_ths=height_ths,
+                  width_ths=width_ths, add_margin=add_margin)
+        heat, ratio = self.heatmap_device(self._to_dev(img[None]), **kw)
+        h, f, _ = self.boxes_from_heatmap(heat, ratio, **kw)
+        return [h[0]], [f[0]]
+
+    def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", detail=1, paragraph=False,
+                  contrast_ths=0.1, adjust_contrast=0.5, reformat=True, **_ignored):
+        """``Reader.recognize`` for explicit boxes of one gray page."""
+        self._unsupported(decoder, None, None, None, paragraph, "standard")
+        if reformat:
+            _, img_cv_grey = reformat_input(img_cv_grey)
+        H, W = img_cv_grey.shape
+        if horizontal_list is None and free_list is None:
+            horizontal_list, free_list = [[0, W, 0, H]], []
+        return self.recognize_device(self._to_dev(img_cv_grey[None]), [horizontal_list or []], [free_list or []],
+                                     contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail)[0]
+
+    # -- stage-level entry points (tests, bench) --------------------------------------------
+    def detect_dims(self, H, W, canvas_size=2560, mag_ratio=1.0):
+        v = [C.c_int() for _ in range(4)]
+        ratio = C.c_double()
+        rc = self._lib.bbocr_detect_dims(H, W, canvas_size, float(mag_ratio), *[C.byref(x) for x in v], C.byref(ratio))
+        if rc != 0:
+            raise ValueError("bad page size")
+        return v[0].value, v[1].value, v[2].value, v[3].value, ratio.value
+
+    def heatmap_device(self, rgb_dev, **kw):
+        """uint8 [B,H,W,3] device tensor -> (fp32 [B,h,w,2] device tensor, ratio)."""
+        B, H, W, _ = rgb_dev.shape
+        _, _, h, w, ratio = self.detect_dims(H, W, kw.get("canvas_size", 2560), kw.get("mag_ratio", 1.0))
+        heat = self._torch.empty((B, h, w, 2), dtype=self._torch.float32, device=self.device)
+        p = self._params(kw)
+        self._check(self._lib.bbocr_detect(self._h, C.c_void_p(rgb_dev.data_ptr()), B, H, W, C.byref(p), C.c_void_p(heat.data_ptr())))
+        return heat, ratio
+
+    def boxes_from_heatmap(self, heat_dev, ratio, **kw):
+        """fp32 [B,h,w,2] device tensor -> (horizontal lists, free lists, polys) per page."""
+        B, h, w, _ = heat_dev.shape
+        p = self._params(kw)
+        bl = C.POINTER(_lib.bbocr_boxlist)()
+        self._check(self._lib.bbocr_boxes(self._h, C.c_void_p(heat_dev.data_ptr()), B, h, w, float(ratio), C.byref(p), C.byref(bl)))
+        try:
+            b = bl.contents
+            hori = [[[b.hori[i * 4 + k] for k in range(4)] for i in range(b.hori_off[n], b.hori_off[n + 1])] for n in range(B)]
+            free = [[[[b.free_q[i * 8 + 2 * k], b.free_q[i * 8 + 2 * k + 1]] for k in range(4)]
+                     for i in range(b.free_off[n], b.free_off[n + 1])] for n in range(B)]
+            polys = [[[b.polys[i * 8 + k] for k in range(8)] for i in range(b.poly_off[n], b.poly_off[n + 1])] for n in range(B)]
+        finally:
+            self._lib.bbocr_free_boxlist(bl)
+        return hori, free, polys
+
+    def recognize_device(self, gray_dev, horizontal_lists, free_lists, **kw):
+        B, H, W = gray_dev.shape
+        n_h = [len(x) for x in horizontal_lists]
+        n_f = [len(x) for x in free_lists]
+        hoff = (C.c_int * (B + 1))(*np.concatenate([[0], np.cumsum(n_h)]).astype(int).tolist())
+        foff = (C.c_int * (B + 1))(*np.concatenate([[0], np.cumsum(n_f)]).astype(int).tolist())
+        poff = (C.c_int * (B + 1))()
+        hflat = [int(v) for page in horizontal_lists for box in page for v in box]
+        fflat = [float(v) for page in free_lists for box in page for pt in box for v in pt]
+        harr = (C.c_int * max(1, len(hflat)))(*hflat)
+        farr = (C.c_double * max(1, len(fflat)))(*fflat)
+        parr = (C.c_int * 8)()
+        bl = _lib.bbocr_boxlist(n_images=B, poly_off=poff, polys=parr, hori_off=hoff, hori=harr, free_off=foff, free_q=farr)
+        p = self._params(kw)
+        res = C.POINTER(_lib.bbocr_result)()
+        self._check(self._lib.bbocr_recognize(self._h, C.c_void_p(gray_dev.data_ptr()), B, H, W, C.byref(bl), C.byref(p), C.byref(res)))
+        return self._collect(res, kw.get("detail", 1))
+
+    @staticmethod
+    def _unsupported(decoder, allowlist, blocklist, rotation_info, paragraph, output_format):
+        if decoder != "greedy":
+            raise NotImplementedError("only decoder='greedy' is implemented (the reference never passes another one)")
+        if allowlist or blocklist or rotation_info or paragraph or output_format != "standard":
+            raise NotImplementedError("allowlist/blocklist/rotation_info/paragraph/output_format are not implemented yet "
+                                      "(the reference calls readtext(path, paragraph=False, batch_size=1, workers=0))")

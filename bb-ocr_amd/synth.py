@@ -1,0 +1,58 @@
+"""Seeded synthetic book pages (nothing can be downloaded, so bench and tests draw their own).
+
+Dark glyph strokes (30 +- 10) on a light noisy background (235 + N(0,4)), rendered with PIL's
+built-in scalable font without anti-aliasing, words laid out explicitly so that word gaps
+(16 px) and line pitch (40 px) leave wide margins for the designed detector weights
+(``weights.designed_craft_state``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_WORDS = ("the quick brown fox jumps over lazy dog beyond frontier romance of early days in middle west chapter "
+          "copyright published october great britain stone first novel harry potter and philosopher express land "
+          "endurance incredible voyage red men iowa dreaming city previously edited version entitled book cover page "
+          "author title publisher edition isbn year library press university history volume series paper print").split()
+
+
+def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_size: int = 24, word_gap: int = 16, line_pitch: int = 40,
+         margin: int = 48):
+    """-> (rgb uint8 [H,W,3], word boxes [(x0,y0,x1,y1,text)])."""
+    from PIL import Image, ImageDraw, ImageFont
+
+    rng = np.random.default_rng(seed)
+    try:
+        font = ImageFont.load_default(size=font_size)
+    except TypeError:  # very old Pillow: bitmap font only
+        font = ImageFont.load_default()
+    mask = Image.new("L", (width, height), 0)
+    draw = ImageDraw.Draw(mask)
+    draw.fontmode = "1"
+    words = []
+    y = margin
+    for _ in range(lines):
+        if y + line_pitch > height - margin // 2:
+            break
+        x = margin + int(rng.integers(0, 24))
+        limit = width - margin - int(rng.integers(0, width // 3))
+        while True:
+            w = _WORDS[int(rng.integers(0, len(_WORDS)))]
+            if rng.random() < 0.15:
+                w = w.capitalize()
+            bb = draw.textbbox((x, y), w, font=font)
+            if bb[2] > limit:
+                break
+            draw.text((x, y), w, fill=255, font=font)
+            words.append((bb[0], bb[1], bb[2], bb[3], w))
+            x = bb[2] + word_gap
+        y += line_pitch
+    m = np.asarray(mask) > 127
+    bg = 235.0 + rng.normal(0.0, 4.0, (height, width))
+    fg = 30.0 + rng.uniform(-10.0, 10.0, (height, width))
+    g = np.where(m, fg, bg)
+    g = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)), words
+
+
+def pages(n: int, seed0: int = 1234, **kw):
+    return np.stack([page(seed0 + i, **kw)[0] for i in range(n)])

@@ -1,0 +1,152 @@
+/* libbbocr -- C ABI of the MI355X-native OCR backend (detector + recogniser) for BB-OCR.
+ *
+ * Drop-in boundary: the L3 -> L1 edge of the reference, i.e. what
+ *     easyocr.Reader(["en"], gpu=...)                     pipeline_demo/extractor/enhanced_extractor.py:153
+ *     reader.readtext(path, paragraph=False, batch_size=1, workers=0)      ...enhanced_extractor.py:520
+ * compute.  The reference has no FFI of its own (it is pure Python on the third-party easyocr==1.7.2,
+ * pipeline_demo/requirements.txt:7); the Python binding a maintainer adds is the ctypes stub shown in
+ * INTEGRATION.md and shipped as bb_ocr_amd/_lib.py.
+ *
+ * Conventions: every entry point returns 0 on success and a negative bbocr_status on failure, never throws and
+ * never aborts (the reference relies on catching exceptions: enhanced_extractor.py:529-531, i2j_ui/app/main.py:631-644);
+ * bbocr_last_error() gives the message.  Image / heat-map pointers are DEVICE pointers (HBM); weight descriptors and
+ * results are HOST memory.  All work of one call is ordered on the context's own HIP stream and the call returns after
+ * that stream has drained.  One context may be used from several threads (calls serialise on an internal mutex);
+ * ctypes releases the GIL around each call.
+ */
+#ifndef BBOCR_H
+#define BBOCR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbocr_ctx bbocr_ctx;
+
+enum bbocr_status {
+    BBOCR_OK = 0,
+    BBOCR_ERR_ARG = -1,      /* bad argument / shape */
+    BBOCR_ERR_HIP = -2,      /* a HIP runtime call failed */
+    BBOCR_ERR_WEIGHTS = -3,  /* missing or mis-shaped tensor in a state-dict */
+    BBOCR_ERR_STATE = -4,    /* weights not loaded, context destroyed, ... */
+    BBOCR_ERR_OVERFLOW = -5, /* a device work buffer was too small (reported, never silent) */
+    BBOCR_ERR_INTERNAL = -6
+};
+
+typedef struct bbocr_config {
+    int device;         /* HIP device ordinal */
+    int det_sub_batch;  /* pages per detector pass; 0 = default (8) */
+    int rec_max_cols;   /* pixel columns per recogniser pass; 0 = default (262144) */
+    int reserved[5];
+} bbocr_config;
+
+/* One tensor of an upstream state-dict (easyocr/craft.py::CRAFT or easyocr/model/vgg_model.py::Model key names,
+ * optional "module." prefix), fp32, host memory, C-contiguous.  Replaces torch.load + load_state_dict in
+ * easyocr/detection.py::get_detector and easyocr/recognition.py::get_recognizer. */
+typedef struct bbocr_tensor_desc {
+    const char* name;
+    int ndim;
+    int64_t shape[4];
+    const float* data;
+} bbocr_tensor_desc;
+
+/* keyword arguments of easyocr.Reader.readtext that affect this path (same names, same defaults) */
+typedef struct bbocr_params {
+    double text_threshold; /* 0.7 */
+    double low_text;       /* 0.4 */
+    double link_threshold; /* 0.4 */
+    double mag_ratio;      /* 1.0 */
+    double slope_ths;      /* 0.1 */
+    double ycenter_ths;    /* 0.5 */
+    double height_ths;     /* 0.5 */
+    double width_ths;      /* 0.5 */
+    double add_margin;     /* 0.1 */
+    double contrast_ths;   /* 0.1 */
+    double adjust_contrast;/* 0.5 */
+    int canvas_size;       /* 2560 */
+    int min_size;          /* 20 */
+    int reserved[4];
+} bbocr_params;
+
+/* output of detection (easyocr.Reader.detect): per image horizontal_list / free_list, plus the ungrouped polygons */
+typedef struct bbocr_boxlist {
+    int n_images;
+    int* poly_off;   /* [n_images+1] */
+    int* polys;      /* [poly_off[n]][8]  int32 x,y x4 (detection.get_textbox output, image coordinates) */
+    int* hori_off;   /* [n_images+1] */
+    int* hori;       /* [hori_off[n]][4]  xmin, xmax, ymin, ymax */
+    int* free_off;   /* [n_images+1] */
+    double* free_q;  /* [free_off[n]][8]  x,y x4 */
+} bbocr_boxlist;
+
+/* output of readtext: boxes in upstream order (horizontal boxes, then free boxes), per image */
+typedef struct bbocr_result {
+    int n_images;
+    int* box_off;     /* [n_images+1] */
+    double* quads;    /* [n_boxes][8]; horizontal boxes are the clamped integer corners */
+    int* is_free;     /* [n_boxes] */
+    int* text_off;    /* [n_boxes+1] into text_idx */
+    int* text_idx;    /* class indices 1..96: position in the english_g2 character list (0 = CTC blank, never emitted) */
+    double* conf;     /* [n_boxes] custom_mean confidence */
+} bbocr_result;
+
+int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out);
+void bbocr_destroy(bbocr_ctx* ctx);
+const char* bbocr_last_error(bbocr_ctx* ctx);
+void bbocr_default_params(bbocr_params* p);
+
+/* which: 0 = CRAFT detector (craft_mlt_25k layout), 1 = CRNN recogniser (english_g2 layout).  BatchNorm is folded,
+ * weights are packed to the MFMA fragment layout in bf16 and uploaded. */
+int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n);
+
+/* geometry of the detector for an H x W page: network input H32 x W32 (after canvas_size scaling, padded to x32),
+ * heat-map h x w = H32/2 x W32/2, ratio as returned by resize_aspect_ratio */
+int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio);
+
+/* S2+S3: uint8 RGB pages [B,H,W,3] (device) -> region/affinity heat-map fp32 [B,h,w,2] (device).
+ * Replaces detection.test_net's resize_aspect_ratio + normalizeMeanVariance + CRAFT.forward. */
+int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, const bbocr_params* p, float* dev_heat_out);
+
+/* S4+S5: heat-map -> boxes.  Replaces craft_utils.getDetBoxes + adjustResultCoordinates + get_textbox +
+ * utils.group_text_box + the min_size filter of Reader.detect.  ratio is the one bbocr_detect_dims returned. */
+int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, double ratio, const bbocr_params* p, bbocr_boxlist** out);
+
+/* S6-S10: gray pages [B,H,W] uint8 (device) + boxes -> text.  Replaces Reader.recognize (per-box branch:
+ * get_image_list, AlignCollate, CRNN forward, softmax, greedy CTC, contrast retry). */
+int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W, const bbocr_boxlist* boxes, const bbocr_params* p,
+                    bbocr_result** out);
+
+/* all stages in one call (== Reader.readtext_batched for equally sized pages).  dev_gray may be NULL: it is then
+ * derived from dev_rgb with cv2's BGR2GRAY fixed-point formula, as upstream does for ndarray input. */
+int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* dev_gray, int B, int H, int W, const bbocr_params* p,
+                         bbocr_result** out);
+
+void bbocr_free_boxlist(bbocr_boxlist* b);
+void bbocr_free_result(bbocr_result* r);
+
+/* milliseconds spent in the last readtext/detect/boxes/recognize call, per stage:
+ * [0] detector net (S2+S3), [1] CCL kernels (S4 device), [2] box geometry + grouping (S4/S5 host),
+ * [3] crops (S6/S7), [4] recogniser net (S8), [5] CTC decode (S9), [6] contrast retry pass, [7] total */
+int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n);
+
+/* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
+/* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
+ * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout). */
+int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                    int KH, int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out);
+/* recogniser network only: crops bf16 [n,64,imgW] (device, already normalised) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
+int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);
+/* greedy CTC on logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n] */
+int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf);
+/* cv2.resize(INTER_LINEAR) on uint8 [N,sh,sw,C] -> [N,dh,dw,C] (device) */
+int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw);
+/* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] for the boxes whose padded width
+ * is imgW (in box order); returns their count in *n_out.  contrast != 0 applies adjust_contrast_grey first. */
+int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free,
+                   int imgW, float contrast, uint16_t* dev_out, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,22 @@
+"""CPU oracle for the BB-OCR hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is a CPU restatement (torch fp32 / numpy / PIL) of the algorithm
+behind ``easyocr.Reader.readtext()`` as it is called from the reference at
+``pipeline_demo/extractor/enhanced_extractor.py:520``.  The arithmetic of that
+call lives in the un-vendored third-party dependency ``easyocr==1.7.2``
+(``pipeline_demo/requirements.txt:7``), with ``opencv-python==4.10.0.84``
+(``:5``) and ``Pillow==10.4.0`` (``:4``) underneath.  None of those sources nor
+the weight files exist under ``/root/reference`` or in this image, so every
+function here restates the *published* upstream algorithm and cites the
+upstream module it follows.
+
+PARITY UNPINNED: the only known-answer data the reference holds for this path
+are 7 (image -> joined text) pairs that need the real
+``craft_mlt_25k.pth`` / ``english_g2.pth`` weights, which are not available
+offline.  The oracle is therefore pinned only against itself (seeded golden
+vectors under ``tests/golden``); `tests/test_golden_replay.py` replays the 7
+pairs when ``BBOCR_WEIGHTS_DIR`` is set.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package.  The product (``bb_ocr_amd``) never does.
+"""
