@@ -80,6 +80,15 @@ struct bbocr_ctx {
     std::string err;
     float times[8] = {0};
 
+    // ---- optional per-launch timing of the conv_mfma kernel (HIP events on this context's stream)
+    struct ProfRec { hipEvent_t e0, e1; double flops; int group; };
+    bool profiling = false;
+    int prof_group = 0;                     // 0 = detector, 1 = recogniser
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
+    long long prof_launches[2] = {0, 0};
+
     // ---- detector
     bool craft_loaded = false;
     uint16_t* c11_w = nullptr;
@@ -301,7 +310,41 @@ static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0,
     a.N = a0.N; a.H = a0.H; a.W = a0.W;
     a.relu_in0 = relu0; a.relu_in1 = relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
     a.out = out; a.out_cs = out_cs; a.cout_store = cout_store;
+    if (!c->profiling) {
+        HIPCHK(launch_conv(p, a, c->stream));
+        return;
+    }
+    auto get_event = [&]() {
+        hipEvent_t e;
+        if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else HIPCHK(hipEventCreate(&e));
+        return e;
+    };
+    bbocr_ctx::ProfRec r;
+    r.e0 = get_event();
+    r.e1 = get_event();
+    const int OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
+    r.flops = 2.0 * a.N * OH * OW * (double)p.Cout * p.Cin * p.KH * p.KW;   // algorithmic (unpadded) work
+    r.group = c->prof_group;
+    HIPCHK(hipEventRecord(r.e0, c->stream));
     HIPCHK(launch_conv(p, a, c->stream));
+    HIPCHK(hipEventRecord(r.e1, c->stream));
+    c->prof_recs.push_back(r);
+}
+
+// after the stream has drained: fold the recorded launches into the per-group totals
+static void prof_collect(bbocr_ctx* c) {
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            c->prof_ms[r.group] += ms;
+            c->prof_flops[r.group] += r.flops;
+            c->prof_launches[r.group] += 1;
+        }
+        c->prof_pool.push_back(r.e0);
+        c->prof_pool.push_back(r.e1);
+    }
+    c->prof_recs.clear();
 }
 
 // conv producing a fresh bf16 activation with `store` channels (multiple of 16)
@@ -329,6 +372,7 @@ static Act up_act(bbocr_ctx* c, const Act& a) {
 // rgb: [nb, Himg, Wimg, 3] on a zero canvas H32 x W32 -> heat fp32 [nb, H32/2, W32/2, 2]
 static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
     Arena& ar = c->arena;
+    c->prof_group = 0;
     Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
     if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->stream));
     Act a2 = conv_act(c, c->conv1_2, a1, false, nullptr, false, true, 64);
@@ -582,6 +626,7 @@ static bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j) {
 // CRNN forward for n normalised crops bf16 [n,64,imgW] -> logits fp32 [n,T,112]
 static void crnn_forward(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, float* logits) {
     Arena& ar = c->arena;
+    c->prof_group = 1;
     const int T = imgW / 4 - 1;
     Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32), n, 32, imgW / 2, 32};
     if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->stream));
@@ -896,6 +941,8 @@ void bbocr_destroy(bbocr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     free_weights(c);
     DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
                       &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
@@ -937,6 +984,7 @@ int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, co
         auto t0 = clk::now();
         detect_impl(ctx, dev_rgb, B, H, W, pp, dev_heat_out);
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        prof_collect(ctx);
         ctx->times[0] = ctx->times[7] = (float)ms_since(t0);
     });
 }
@@ -970,6 +1018,7 @@ int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W
         std::vector<BoxJob> jobs;
         std::vector<int> off;
         recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        prof_collect(ctx);
         *out = export_result(B, jobs, off);
         ctx->times[7] = (float)ms_since(t0);
     });
@@ -1000,6 +1049,7 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
         std::vector<BoxJob> jobs;
         std::vector<int> off;
         recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        prof_collect(ctx);
         *out = export_result(B, jobs, off);
         ctx->times[7] = (float)ms_since(t_all);
     });
@@ -1015,6 +1065,23 @@ void bbocr_free_result(bbocr_result* r) {
     if (!r) return;
     free(r->box_off); free(r->quads); free(r->is_free); free(r->text_off); free(r->text_idx); free(r->conf);
     free(r);
+}
+
+int bbocr_set_profiling(bbocr_ctx* ctx, int on) {
+    if (!ctx) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = on != 0;
+    for (int g = 0; g < 2; ++g) { ctx->prof_ms[g] = 0; ctx->prof_flops[g] = 0; ctx->prof_launches[g] = 0; }
+    return BBOCR_OK;
+}
+
+int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches) {
+    if (!ctx || group < 0 || group > 1) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ms) *ms = ctx->prof_ms[group];
+    if (flops) *flops = ctx->prof_flops[group];
+    if (launches) *launches = ctx->prof_launches[group];
+    return BBOCR_OK;
 }
 
 int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n) {

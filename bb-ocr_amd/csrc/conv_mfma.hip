@@ -240,16 +240,25 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     a.OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil;
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
-    a.TH = a.OH > 8 ? 16 : (a.OH > 4 ? 8 : 4);
-    a.TW = BM / a.TH;
+    a.ntaps = p.KH * p.KW;
+    // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
+    {
+        long long best = -1;
+        for (int th = 16; th >= 4; th >>= 1) {
+            const int tw = BM / th;
+            const int ph = th + (p.KH - 1) * p.dil, pw = tw + (p.KW - 1) * p.dil;
+            const int np = cdiv(ph * pw, 16) * 16;
+            if (cdiv(np / 16, 8) > 8) continue;
+            const long long tiles = (long long)cdiv(a.OH, th) * cdiv(a.OW, tw);
+            const long long cost = tiles * ((long long)BM * a.ntaps + 2LL * np);
+            if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = np; }
+        }
+        if (best < 0) return hipErrorInvalidValue;
+    }
     a.tiles_x = cdiv(a.OW, a.TW);
     a.tiles_y = cdiv(a.OH, a.TH);
     a.ntiles_n = p.Cout_pad / BN;
-    a.PH = a.TH + (p.KH - 1) * p.dil;
-    a.PW = a.TW + (p.KW - 1) * p.dil;
-    a.NP = cdiv(a.PH * a.PW, 16) * 16;
     a.nchunks = p.Cin_pad / 32;
-    a.ntaps = p.KH * p.KW;
     if (a.C0 + a.C1 != p.Cin_pad || (a.C0 & 31) || (a.C1 & 31)) return hipErrorInvalidValue;
     if ((a.in0_cs & 7) || (a.C1 && (a.in1_cs & 7)) || (a.out_cs & (a.out_f32 ? 3 : 7)) || (a.cout_store & 15)) return hipErrorInvalidValue;
     a.wpk = p.d_w;

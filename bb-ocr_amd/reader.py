@@ -177,6 +177,16 @@ class Reader:
         keys = ("detector_net", "ccl_device", "box_geometry_host", "crops", "recognizer_net", "ctc", "contrast_retry", "total")
         return dict(zip(keys, [float(v) for v in ms]))
 
+    def set_profiling(self, on: bool):
+        """Time every conv_mfma launch with HIP events on the library's stream (bench.py roofline leg)."""
+        self._check(self._lib.bbocr_set_profiling(self._h, int(bool(on))))
+
+    def conv_profile(self, group: int):
+        """-> (sum of launch ms, sum of algorithmic flops, launches) for group 0 (detector) / 1 (recogniser)."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
+        self._check(self._lib.bbocr_conv_profile(self._h, group, C.byref(ms), C.byref(fl), C.byref(n)))
+        return ms.value, fl.value, n.value
+
     # -- easyocr surface ---------------------------------------------------------------
     def readtext_device(self, rgb_dev, gray_dev=None, **kw):
         """Batch entry for pages already resident in HBM: uint8 torch tensors [B,H,W,3] (+ optional [B,H,W])."""

@@ -130,6 +130,12 @@ void bbocr_free_result(bbocr_result* r);
  * [3] crops (S6/S7), [4] recogniser net (S8), [5] CTC decode (S9), [6] contrast retry pass, [7] total */
 int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n);
 
+/* Per-launch timing of the dominant kernel (conv_mfma) with HIP events recorded on the context's stream.
+ * group 0 = detector convs, 1 = recogniser convs/GEMMs.  Totals accumulate from bbocr_set_profiling(ctx, 1) on:
+ * ms = sum of launch durations, flops = sum of ALGORITHMIC flops (2*N*OH*OW*Cout*Cin*KH*KW, unpadded). */
+int bbocr_set_profiling(bbocr_ctx* ctx, int on);
+int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches);
+
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
  * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout). */

@@ -1,0 +1,104 @@
+"""-m gpu: single kernels through the C ABI against the oracle / torch fp32 on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _conv_case(reader, N, H, W, Cin, Cout, K, pad, dil, relu_in, relu_out, out_f32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = _bf16(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, K, K, generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wq = _bf16(w)
+    xin = F.relu(x) if relu_in else x
+    ref = F.conv2d(xin.double(), wq.double(), b.double(), padding=pad, dilation=dil)
+    if relu_out:
+        ref = F.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).float()
+    OH, OW = ref.shape[1:3]
+    store = (Cout + 15) // 16 * 16
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    out = torch.full((N, OH, OW, store), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    wn = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bn = np.ascontiguousarray(b.numpy(), dtype=np.float32)
+    rc = reader._lib.bbocr_op_conv2d(reader._h, C.c_void_p(xd.data_ptr()), N, H, W, Cin, wn.ctypes.data_as(C.POINTER(C.c_float)),
+                                     bn.ctypes.data_as(C.POINTER(C.c_float)), Cout, K, K, pad, dil, int(relu_in), int(relu_out), int(out_f32),
+                                     C.c_void_p(out.data_ptr()))
+    reader._check(rc)
+    got = out.float().cpu()[..., :Cout]
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    tol = (2e-5 if out_f32 else 6e-3) * max(scale, 1.0)     # fp32 accumulate; bf16 output rounding 2^-8 relative
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"conv err {err} > {tol} (scale {scale})"
+    if store > Cout:
+        pad_part = out.float().cpu()[..., Cout:]
+        assert torch.isfinite(pad_part).all()
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, K, pad, dil, relu_in, relu_out, out_f32
+    (1, 16, 16, 32, 64, 3, 1, 1, 0, 1, 0),      # BN=64 tile, exact tile
+    (2, 19, 37, 64, 64, 3, 1, 1, 0, 1, 0),      # ragged edges, 2 chunks
+    (1, 24, 40, 64, 128, 3, 1, 1, 1, 0, 0),     # BN=128, ReLU on load
+    (1, 20, 28, 128, 256, 3, 1, 1, 0, 1, 0),    # BN=256
+    (1, 17, 23, 256, 512, 3, 1, 1, 0, 0, 0),    # two cout tiles
+    (1, 15, 20, 64, 256, 3, 6, 6, 0, 0, 0),     # dilation 6 (fc6)
+    (2, 12, 20, 96, 256, 1, 0, 1, 0, 1, 0),     # 1x1
+    (1, 4, 70, 64, 256, 2, 0, 1, 0, 1, 0),      # 2x2 valid (CRNN last conv), short tile rows
+    (1, 8, 50, 128, 256, 3, 1, 1, 0, 1, 0),     # H = 8 tile
+    (1, 9, 33, 32, 32, 3, 1, 1, 0, 1, 0),       # Cout 32 (store 32 of a 64 tile)
+    (1, 9, 33, 32, 16, 3, 1, 1, 0, 1, 0),       # Cout 16
+    (1, 5, 40, 256, 97, 1, 0, 1, 0, 0, 1),      # prediction layer, fp32 out, Cout 97 -> 112
+    (1, 30, 45, 256, 2048, 1, 0, 1, 0, 0, 0),   # LSTM input projection shape
+])
+def test_conv_mfma_vs_fp64(reader, cfg):
+    _conv_case(reader, *cfg)
+
+
+def test_resize_u8_bit_exact(reader):
+    from oracle import imgproc
+
+    rng = np.random.default_rng(3)
+    for (sh, sw, dh, dw, c) in [(37, 53, 64, 91, 1), (120, 200, 64, 107, 1), (64, 64, 32, 32, 1), (50, 70, 50, 70, 3), (91, 47, 40, 33, 3),
+                                (13, 300, 64, 1477, 1)]:
+        src = rng.integers(0, 256, (2, sh, sw, c), dtype=np.uint8)
+        d = torch.from_numpy(src).cuda()
+        out = torch.zeros((2, dh, dw, c), dtype=torch.uint8, device="cuda")
+        reader._check(reader._lib.bbocr_op_resize_u8(reader._h, C.c_void_p(d.data_ptr()), 2, sh, sw, c, C.c_void_p(out.data_ptr()), dh, dw))
+        got = out.cpu().numpy()
+        for n in range(2):
+            ref = imgproc.resize_linear_u8(src[n] if c > 1 else src[n, :, :, 0], (dw, dh))
+            assert np.array_equal(got[n] if c > 1 else got[n, :, :, 0], ref), (sh, sw, dh, dw, c)
+
+
+def test_ctc_matches_oracle(reader):
+    from oracle import recog
+
+    rng = np.random.default_rng(5)
+    n, T, Cn, cs = 7, 83, 97, 112
+    logits = (rng.standard_normal((n, T, cs)) * 4).astype(np.float32)
+    # force repeats, blanks and an all-blank row
+    logits[0, :, 0] += 30.0
+    logits[1, 10:30, 5] += 30.0
+    logits[2, ::2, 0] += 30.0
+    d = torch.from_numpy(logits).cuda()
+    off = (C.c_int * (n + 1))()
+    idx = (C.c_int * (n * T))()
+    conf = (C.c_double * n)()
+    reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf))
+    ref = recog.predict_from_logits(logits[:, :, :Cn])
+    for i in range(n):
+        text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
+        assert text == ref[i][0]
+        assert conf[i] == pytest.approx(float(ref[i][1]), rel=2e-5, abs=1e-12)
+    assert off[1] - off[0] == 0 and conf[0] == 0.0

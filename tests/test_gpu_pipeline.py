@@ -1,0 +1,209 @@
+"""-m gpu: stage and end-to-end parity of the HIP path (through the C ABI) against the oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HEAT_TOL = 0.03   # max |heat - oracle fp32| on designed-weight pages (bf16 storage, fp32 accumulate; values span 0..6)
+
+
+def _synth_heat(rng, h, w, nblobs=26):
+    """Region/affinity maps with axis-aligned and rotated strokes, touching image borders, tiny specks and link bridges."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    text = np.zeros((h, w), np.float32)
+    link = np.zeros((h, w), np.float32)
+    for _ in range(nblobs):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        lw, lh = rng.uniform(3, 20), rng.uniform(2, 5)
+        ang = rng.choice([0.0, 0.0, 0.0, rng.uniform(-0.6, 0.6)])
+        ca, sa = math.cos(ang), math.sin(ang)
+        u = (xx - cx) * ca + (yy - cy) * sa
+        v = -(xx - cx) * sa + (yy - cy) * ca
+        d = np.maximum(np.abs(u) / lw, np.abs(v) / lh)
+        amp = rng.uniform(0.75, 1.3)
+        text = np.maximum(text, amp * np.clip(1.4 - d, 0, 1))
+        if rng.random() < 0.5:
+            link = np.maximum(link, 0.9 * np.clip(1.6 - np.maximum(np.abs(u - lw) / (0.8 * lw), np.abs(v) / lh), 0, 1))
+    text += rng.normal(0, 0.01, text.shape).astype(np.float32)
+    return text.astype(np.float32), link.astype(np.float32)
+
+
+def test_boxes_bit_exact_given_heatmap(reader):
+    from oracle import boxes as obox
+
+    rng = np.random.default_rng(11)
+    B, h, w = 3, 160, 288
+    heat = np.zeros((B, h, w, 2), np.float32)
+    for b in range(B):
+        heat[b, ..., 0], heat[b, ..., 1] = _synth_heat(rng, h, w)
+    heat[2] = 0.0                                    # empty page
+    d = torch.from_numpy(heat).cuda()
+    for ratio, kw in [(1.0, {}), (0.7306, {"min_size": 10, "add_margin": 0.2})]:
+        hori, free, polys = reader.boxes_from_heatmap(d, ratio, **kw)
+        nfree = 0
+        for b in range(B):
+            oh, of, op = obox.detect_from_heatmap(heat[b, ..., 0], heat[b, ..., 1], ratio, **kw)
+            assert [list(map(int, p)) for p in op] == polys[b]
+            assert [list(map(int, x)) for x in oh] == hori[b]
+            assert len(of) == len(free[b])
+            for a, g in zip(of, free[b]):
+                assert np.allclose(np.array(a, dtype=np.float64), np.array(g), rtol=0, atol=1e-9)
+            nfree += len(of)
+        assert len(polys[0]) > 5 and polys[2] == []
+    assert nfree > 0, "the fixture must exercise the free (slanted) box branch"
+
+
+def test_heatmap_within_tolerance(reader, oracle_reader):
+    from bb_ocr_amd import synth
+
+    imgs = np.stack([synth.page(21 + i, width=384, height=256, lines=5, margin=24)[0] for i in range(3)])
+    heat, ratio = reader.heatmap_device(torch.from_numpy(imgs).cuda())
+    got = heat.cpu().numpy()
+    for i in range(3):
+        st, sl, r2 = oracle_reader.heatmap(imgs[i])
+        assert ratio == r2
+        assert np.abs(got[i, ..., 0] - st).max() <= HEAT_TOL
+        assert np.abs(got[i, ..., 1] - sl).max() <= HEAT_TOL * 2
+        assert st.max() > 0.7
+
+
+def test_heatmap_random_weights_relative(reader):
+    """Fully random detector (no designed channels): relative L2 error of the heat-map vs torch fp32."""
+    import bb_ocr_amd
+    from bb_ocr_amd import synth, weights
+    from oracle import pipeline
+
+    cs, rs = weights.synthetic_craft_state(3), weights.synthetic_crnn_state(3)
+    r = bb_ocr_amd.Reader(["en"], weights=(cs, rs))
+    ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
+    img = synth.page(5, width=352, height=224, lines=4, margin=24)[0]       # 224 = 7*32: odd tile counts at every level
+    heat, _ = r.heatmap_device(torch.from_numpy(img[None]).cuda())
+    st, sl, _ = ref.heatmap(img)
+    got = heat[0].cpu().numpy()
+    want = np.stack([st, sl], -1)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 4e-2, rel      # 27 bf16-stored layers (each ~2^-9 relative rounding), fp32 accumulate
+    r.close()
+
+
+def test_detector_resize_path(reader, oracle_reader):
+    """Page larger than canvas_size: cv2-style resize + zero canvas padding before the network."""
+    from bb_ocr_amd import synth
+
+    img = synth.page(9, width=500, height=300, lines=5, margin=24)[0]
+    heat, ratio = reader.heatmap_device(torch.from_numpy(img[None]).cuda(), canvas_size=320)
+    st, sl, r2 = oracle_reader.heatmap(img, canvas_size=320)
+    assert ratio == r2 and heat.shape[1:3] == st.shape
+    got = heat[0].cpu().numpy()
+    assert np.abs(got[..., 0] - st).max() <= HEAT_TOL * 2
+
+
+def _crops_case(reader, grey, hori, free, contrast):
+    from oracle import recog
+
+    H, W = grey.shape
+    d = torch.from_numpy(grey).cuda()
+    items = []
+    for b in hori:
+        il, mw = recog.get_image_list([b], [], grey)
+        if il:
+            items.append((il[0][1], int(mw)))
+    for f in free:
+        il, mw = recog.get_image_list([], [f], grey)
+        if il:
+            items.append((il[0][1], int(mw)))
+    widths = sorted({mw for _, mw in items})
+    harr = (C.c_int * max(1, 4 * len(hori)))(*[int(v) for b in hori for v in b])
+    farr = (C.c_double * max(1, 8 * len(free)))(*[float(v) for f in free for p in f for v in p])
+    total = 0
+    for mw in widths:
+        want = [recog.align_collate_one(c, 64, mw, adjust_contrast=contrast) for c, m in items if m == mw]
+        out = torch.zeros((len(want), 64, mw), dtype=torch.bfloat16, device="cuda")
+        n_out = C.c_int()
+        reader._check(reader._lib.bbocr_op_crops(reader._h, C.c_void_p(d.data_ptr()), H, W, harr, len(hori), farr, len(free), mw, float(contrast),
+                                                 C.c_void_p(out.data_ptr()), C.byref(n_out)))
+        assert n_out.value == len(want)
+        got = out.cpu()
+        ref = torch.from_numpy(np.concatenate(want, 0)).to(torch.bfloat16)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), f"crop bucket {mw} differs"
+        total += len(want)
+    return total
+
+
+def test_crops_bit_exact(reader):
+    from bb_ocr_amd import synth
+
+    img = synth.page(33, width=640, height=400, lines=8, margin=30)[0]
+    grey = np.ascontiguousarray(img[..., 0])
+    hori = [[40, 300, 30, 62], [-5, 200, 70, 100], [300, 660, 380, 410], [100, 420, 150, 171], [50, 62, 40, 120], [200, 232, 100, 300],
+            [10, 74, 200, 264], [320, 600, 200, 216]]
+    free = [[[100.0, 50.0], [400.0, 80.0], [395.0, 120.0], [95.0, 90.0]], [[300.5, 200.2], [340.0, 190.0], [350.0, 300.0], [310.0, 310.0]]]
+    assert _crops_case(reader, grey, hori, free, 0.0) == len(hori) + len(free)
+    assert _crops_case(reader, grey, hori, free, 0.5) == len(hori) + len(free)
+
+
+def test_crnn_logits_within_tolerance(reader, oracle_reader):
+    rng = np.random.default_rng(17)
+    for n, W in [(3, 128), (2, 320)]:
+        x = (rng.integers(0, 256, (n, 1, 64, W)).astype(np.float32) / 255.0 - 0.5) / 0.5
+        # smooth it a little so it looks like text strokes rather than white noise
+        x = (x + np.roll(x, 1, 3) + np.roll(x, 1, 2)) / 3.0
+        xb = torch.from_numpy(x).to(torch.bfloat16)
+        ref = oracle_reader._logits(xb.float().numpy())
+        T = W // 4 - 1
+        out = torch.zeros((n, T, 112), dtype=torch.float32, device="cuda")
+        reader._check(reader._lib.bbocr_crnn_logits(reader._h, C.c_void_p(xb[:, 0].contiguous().cuda().data_ptr()), n, W, C.c_void_p(out.data_ptr())))
+        got = out.cpu().numpy()[:, :, :97]
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel < 3e-2, rel
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def test_readtext_end_to_end(reader, oracle_reader):
+    """Whole path on designed-weight pages: boxes identical to the oracle's; text compared per character."""
+    from bb_ocr_amd import synth
+
+    agree = total = 0
+    for seed in (101, 102):
+        img = synth.page(seed, width=512, height=320, lines=6, margin=24)[0]
+        got = reader.readtext(img)
+        want = oracle_reader.readtext(img)
+        assert [g[0] for g in got] == [[list(map(int, p)) for p in w[0]] for w in want]
+        for (_, tg, cg), (_, tw, cw) in zip(got, want):
+            total += max(len(tg), len(tw))
+            agree += max(len(tg), len(tw)) - _edit_distance(tg, tw)
+        assert len(got) >= 4
+    # random-weight recogniser in bf16 vs fp32: arg-max flips happen where the top-2 margin is below the bf16 noise,
+    # so text identity is statistical here; the exact checks are the stage tests (CTC given logits, boxes given heat-map)
+    print("character agreement", agree, total)
+    assert agree / max(total, 1) > 0.5, (agree, total)
+
+
+def test_readtext_batched_matches_single(reader):
+    from bb_ocr_amd import synth
+
+    imgs = [synth.page(200 + i, width=384, height=256, lines=5, margin=24)[0] for i in range(3)]
+    single = [reader.readtext(im) for im in imgs]
+    batched = reader.readtext_batched(imgs)
+    assert batched == single
+
+
+def test_error_paths_raise(reader):
+    with pytest.raises(ValueError):
+        reader.readtext(np.zeros((4, 4), dtype=np.float32))
+    with pytest.raises(NotImplementedError):
+        reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), decoder="beamsearch")
+    assert reader.readtext(np.full((64, 96, 3), 235, dtype=np.uint8)) == []      # blank page: no boxes, no error
