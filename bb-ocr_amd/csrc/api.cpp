@@ -108,6 +108,7 @@ struct bbocr_ctx {
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
     DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
     DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out;
+    DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
 
 namespace {
@@ -623,8 +624,8 @@ static bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j) {
     return d.rw > 0 && d.rh > 0 && d.fw > 0;
 }
 
-// CRNN forward for n normalised crops bf16 [n,64,imgW] -> logits fp32 [n,T,112]
-static void crnn_forward(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, float* logits) {
+// conv stack of the recogniser for n normalised crops of one padded width: bf16 [n,64,imgW] -> v bf16 [n*T, 256]
+static void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_t* v_out) {
     Arena& ar = c->arena;
     c->prof_group = 1;
     const int T = imgW / 4 - 1;
@@ -639,21 +640,34 @@ static void crnn_forward(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, f
     Act c5 = conv_act(c, c->r5, c4, false, nullptr, false, true, 256);
     Act q3 = pool_act(c, c5, 2, 1, 2, 1, 0, 0, false);
     Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [n,3,T,256]
-    Act v{ar.alloc<uint16_t>((size_t)n * T * 256), 1, n, T, 256};           // sequences as rows of one "image"
-    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v.p, n, T, 256, c->stream));
-    Act cur = v;
+    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->stream));
+}
+
+// Sequence half of the recogniser over the POOLED time steps of every bucket (rows = sum n_i*T_i, padded to x256):
+// v bf16 [rows,256] (ctx->seq_v) -> logits fp32 [rows,112].  The two linear layers and both input projections are
+// single GEMMs over all rows; each BiLSTM layer is ONE launch whose workgroups carry their own sequence length.
+static void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, int ntiles, float* logits) {
+    c->prof_group = 1;
+    c->arena.dry = false;
+    c->seq_xp.ensure(rows_pad * 2048 * 2);
+    c->seq_h.ensure(rows_pad * 512 * 2);
+    c->seq_lin.ensure(rows_pad * 256 * 2);
+    const int Hh = (int)(rows_pad / 256);
+    Act cur{(uint16_t*)c->seq_v.p, 1, Hh, 256, 256};
     for (int l = 0; l < 2; ++l) {
-        Act xp = conv_act(c, c->xproj[l], cur, false, nullptr, false, false, 2048);
-        Act hh{ar.alloc<uint16_t>((size_t)n * T * 512), 1, n, T, 512};
-        if (!ar.dry) HIPCHK(launch_lstm(xp.p, c->whh[l], hh.p, n, T, c->stream));
-        cur = conv_act(c, c->lin[l], hh, false, nullptr, false, false, 256);
+        run_conv(c, c->xproj[l], cur, false, nullptr, false, false, c->seq_xp.p, 2048, 2048, false);
+        HIPCHK(launch_lstm((const uint16_t*)c->seq_xp.p, c->whh[l], (uint16_t*)c->seq_h.p, tiles_dev, ntiles, c->stream));
+        Act hh{(uint16_t*)c->seq_h.p, 1, Hh, 256, 512};
+        uint16_t* dst = (uint16_t*)(l == 0 ? c->seq_lin.p : c->seq_v.p);
+        run_conv(c, c->lin[l], hh, false, nullptr, false, false, dst, 256, 256, false);
+        cur.p = dst;
     }
     run_conv(c, c->pred, cur, false, nullptr, false, false, logits, 112, 112, true);
 }
 
-struct Bucket {
-    int imgW;
-    std::vector<int> jobs;   // indices into the job array
+struct RecChunk {
+    int imgW, T, first, n;   // descriptors [first, first+n) share the padded width imgW
+    size_t row0;             // first pooled row of the chunk inside its group
 };
 
 // run one recognition pass over `sel` (indices into jobs); descs must already carry lut_off for a contrast pass.
@@ -665,25 +679,29 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
     // bucket by padded width, keep box order inside a bucket
     std::map<int, std::vector<int>> buckets;
     for (size_t k = 0; k < sel.size(); ++k) buckets[jobs[sel[k]].d.imgW].push_back((int)k);
-    // descriptor table in bucket order
     std::vector<CropDesc> descs;
     std::vector<int> order;   // position k in sel for each descriptor
     descs.reserve(sel.size());
-    for (auto& kv : buckets)
-        for (int k : kv.second) { descs.push_back(jobs[sel[k]].d); order.push_back(k); }
     const int max_cols = c->cfg.rec_max_cols > 0 ? c->cfg.rec_max_cols : 262144;
-    c->crop_desc.ensure(descs.size() * sizeof(CropDesc));
-    auto t0 = clk::now();
-    size_t pos = 0;
+    const size_t max_rows = 1500000;   // pooled time steps per sequence pass (~6.6 KB of work buffers each)
+    std::vector<RecChunk> chunks;
     for (auto& kv : buckets) {
         const int imgW = kv.first, T = imgW / 4 - 1;
         const int per = std::max(1, max_cols / imgW);
         for (size_t s0 = 0; s0 < kv.second.size(); s0 += per) {
             const int n = (int)std::min<size_t>(per, kv.second.size() - s0);
-            for (int i = 0; i < n; ++i) descs[pos + s0 + i].slot = i;
+            chunks.push_back({imgW, T, (int)descs.size(), n, 0});
+            for (int i = 0; i < n; ++i) {
+                const int k = kv.second[s0 + i];
+                CropDesc d = jobs[sel[k]].d;
+                d.slot = i;
+                descs.push_back(d);
+                order.push_back(k);
+            }
         }
-        pos += kv.second.size();
     }
+    c->crop_desc.ensure(descs.size() * sizeof(CropDesc));
+    auto t0 = clk::now();
     HIPCHK(hipMemcpyAsync(c->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
     bool any_warp = false, any_tall = false;
     for (const CropDesc& d : descs) {
@@ -695,55 +713,87 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
                             (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, nullptr, 1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->times[3] += (float)ms_since(t0);
-    pos = 0;
-    for (auto& kv : buckets) {
-        const int imgW = kv.first, T = imgW / 4 - 1;
-        const int per = std::max(1, max_cols / imgW);
-        for (size_t s0 = 0; s0 < kv.second.size(); s0 += per) {
-            const int n = (int)std::min<size_t>(per, kv.second.size() - s0);
-            const int first = (int)(pos + s0);
-            // size the arena, then run
+
+    size_t g0 = 0;
+    while (g0 < chunks.size()) {
+        // group of chunks whose pooled rows fit one sequence pass
+        size_t g1 = g0, rows = 0;
+        while (g1 < chunks.size() && (g1 == g0 || rows + (size_t)chunks[g1].n * chunks[g1].T <= max_rows)) {
+            chunks[g1].row0 = rows;
+            rows += (size_t)chunks[g1].n * chunks[g1].T;
+            ++g1;
+        }
+        const size_t rows_pad = align_up(rows, 256);
+        c->seq_v.ensure(rows_pad * 256 * 2);
+        c->seq_logits.ensure(rows_pad * 112 * 4);
+        t0 = clk::now();
+        std::vector<int> tiles, seqs;   // int4 / int2 tables
+        std::vector<int> seq_k;         // sel position of each pooled sequence
+        for (size_t ci = g0; ci < g1; ++ci) {
+            const RecChunk& ch = chunks[ci];
             uint16_t* crops = nullptr;
-            float* logits = nullptr;
             for (int pass = 0; pass < 2; ++pass) {
                 c->arena.begin(pass == 0);
-                crops = c->arena.alloc<uint16_t>((size_t)n * 64 * imgW);
-                logits = c->arena.alloc<float>((size_t)n * T * 112);
-                if (pass == 1) {
-                    t0 = clk::now();
-                    HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, first, n, imgW, any_warp, any_tall,
+                crops = c->arena.alloc<uint16_t>((size_t)ch.n * 64 * ch.imgW);
+                if (pass == 1)
+                    HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, ch.first, ch.n, ch.imgW, any_warp, any_tall,
                                         (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
                                         (const uint8_t*)c->crop_luts.p, crops, 2, c->stream));
-                    HIPCHK(hipStreamSynchronize(c->stream));
-                    c->times[3] += (float)ms_since(t0);
-                    t0 = clk::now();
-                }
-                crnn_forward(c, crops, n, imgW, logits);
+                crnn_features(c, crops, ch.n, ch.imgW, (uint16_t*)c->seq_v.p + ch.row0 * 256);
                 if (pass == 0) c->arena.buf.ensure(c->arena.off);
             }
-            HIPCHK(hipStreamSynchronize(c->stream));
-            c->times[4] += (float)ms_since(t0);
-            t0 = clk::now();
-            c->ctc_idx.ensure((size_t)n * T * 4);
-            c->ctc_pmax.ensure((size_t)n * T * 4);
-            c->ctc_out_idx.ensure((size_t)n * T * 4);
-            c->ctc_out.ensure((size_t)n * sizeof(CtcOut));
-            HIPCHK(launch_ctc(logits, n, T, 97, 112, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p, (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p,
-                              c->stream));
-            std::vector<int> oidx((size_t)n * T);
-            std::vector<CtcOut> oo(n);
-            HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (int i = 0; i < n; ++i) {
-                const int k = order[first + i];
-                texts[k].assign(oidx.begin() + (size_t)i * T, oidx.begin() + (size_t)i * T + oo[i].len);
-                // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
-                confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
+            for (int s0 = 0; s0 < ch.n; s0 += 16) {
+                tiles.push_back((int)(ch.row0 + (size_t)s0 * ch.T));
+                tiles.push_back(std::min(16, ch.n - s0));
+                tiles.push_back(ch.T);
+                tiles.push_back(0);
             }
-            c->times[5] += (float)ms_since(t0);
+            for (int i = 0; i < ch.n; ++i) {
+                seqs.push_back((int)(ch.row0 + (size_t)i * ch.T));
+                seqs.push_back(ch.T);
+                seq_k.push_back(order[ch.first + i]);
+            }
         }
-        pos += kv.second.size();
+        // longest sequences first: the launch ends with the shortest tails
+        {
+            const size_t nt = tiles.size() / 4;
+            std::vector<size_t> perm(nt);
+            for (size_t i = 0; i < nt; ++i) perm[i] = i;
+            std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) { return tiles[x * 4 + 2] > tiles[y * 4 + 2]; });
+            std::vector<int> t2(tiles.size());
+            for (size_t i = 0; i < nt; ++i) memcpy(&t2[i * 4], &tiles[perm[i] * 4], 16);
+            tiles.swap(t2);
+        }
+        const int ntiles = (int)(tiles.size() / 4), nseq = (int)(seqs.size() / 2);
+        c->seq_tables.ensure((tiles.size() + seqs.size()) * 4);
+        int* tiles_dev = (int*)c->seq_tables.p;
+        int* seqs_dev = tiles_dev + tiles.size();
+        HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->times[4] += (float)ms_since(t0);
+        t0 = clk::now();
+        c->ctc_idx.ensure(rows * 4);
+        c->ctc_pmax.ensure(rows * 4);
+        c->ctc_out_idx.ensure(rows * 4);
+        c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
+        HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
+                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream));
+        std::vector<int> oidx(rows);
+        std::vector<CtcOut> oo(nseq);
+        HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < nseq; ++i) {
+            const int k = seq_k[i];
+            const size_t r0 = (size_t)seqs[2 * i];
+            texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
+            // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
+            confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
+        }
+        c->times[5] += (float)ms_since(t0);
+        g0 = g1;
     }
 }
 
@@ -946,7 +996,8 @@ void bbocr_destroy(bbocr_ctx* c) {
     free_weights(c);
     DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
                       &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
-                      &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out};
+                      &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
+                      &c->seq_tables};
     for (DevBuf* b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1114,11 +1165,23 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
     return guarded(ctx, [&] {
         if (!ctx->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
         if (!dev_crops || !dev_logits || n <= 0 || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop batch");
+        const int T = imgW / 4 - 1;
+        const size_t rows = (size_t)n * T, rows_pad = align_up(rows, 256);
+        ctx->seq_v.ensure(rows_pad * 256 * 2);
+        ctx->seq_logits.ensure(rows_pad * 112 * 4);
         ctx->arena.begin(true);
-        crnn_forward(ctx, dev_crops, n, imgW, dev_logits);
+        crnn_features(ctx, dev_crops, n, imgW, nullptr);
         ctx->arena.buf.ensure(ctx->arena.off);
         ctx->arena.begin(false);
-        crnn_forward(ctx, dev_crops, n, imgW, dev_logits);
+        crnn_features(ctx, dev_crops, n, imgW, (uint16_t*)ctx->seq_v.p);
+        std::vector<int> tiles;
+        for (int s0 = 0; s0 < n; s0 += 16) {
+            tiles.push_back(s0 * T); tiles.push_back(std::min(16, n - s0)); tiles.push_back(T); tiles.push_back(0);
+        }
+        ctx->seq_tables.ensure(tiles.size() * 4);
+        HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        crnn_sequence(ctx, rows_pad, (const int*)ctx->seq_tables.p, (int)(tiles.size() / 4), (float*)ctx->seq_logits.p);
+        HIPCHK(hipMemcpyAsync(dev_logits, ctx->seq_logits.p, rows * 112 * 4, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     });
 }
@@ -1126,13 +1189,18 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
 int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf) {
     return guarded(ctx, [&] {
         if (!dev_logits || !text_off || !text_idx || !conf || n <= 0 || T <= 0 || C <= 0 || C > cs) fail(BBOCR_ERR_ARG, "bad ctc arguments");
-        ctx->ctc_idx.ensure((size_t)n * T * 4);
-        ctx->ctc_pmax.ensure((size_t)n * T * 4);
-        ctx->ctc_out_idx.ensure((size_t)n * T * 4);
+        const size_t rows = (size_t)n * T;
+        ctx->ctc_idx.ensure(rows * 4);
+        ctx->ctc_pmax.ensure(rows * 4);
+        ctx->ctc_out_idx.ensure(rows * 4);
         ctx->ctc_out.ensure((size_t)n * sizeof(CtcOut));
-        HIPCHK(launch_ctc(dev_logits, n, T, C, cs, (int*)ctx->ctc_idx.p, (float*)ctx->ctc_pmax.p, (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p,
-                          ctx->stream));
-        std::vector<int> oidx((size_t)n * T);
+        std::vector<int> seqs;
+        for (int i = 0; i < n; ++i) { seqs.push_back(i * T); seqs.push_back(T); }
+        ctx->seq_tables.ensure(seqs.size() * 4);
+        HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(launch_ctc(dev_logits, rows, C, cs, (const int*)ctx->seq_tables.p, n, (int*)ctx->ctc_idx.p, (float*)ctx->ctc_pmax.p,
+                          (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p, ctx->stream));
+        std::vector<int> oidx(rows);
         std::vector<CtcOut> oo(n);
         HIPCHK(hipMemcpyAsync(oidx.data(), ctx->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(oo.data(), ctx->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, ctx->stream));

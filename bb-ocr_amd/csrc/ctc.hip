@@ -42,13 +42,17 @@ __global__ void __launch_bounds__(256) ctc_rows_kernel(const float* __restrict__
 
 // one wave per sequence: collapse repeats / blanks with ballot + prefix popcount; confidence product kept strictly
 // sequential in t (float32), as numpy's multiply.reduce does.
-__global__ void __launch_bounds__(64) ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ pmax, int n, int T,
-                                                          int* __restrict__ out_idx, CtcOut* __restrict__ out) {
+// seqs[i] = {first row, T}: sequences of different lengths (buckets) share one launch
+__global__ void __launch_bounds__(64) ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ pmax,
+                                                          const int2* __restrict__ seqs, int* __restrict__ out_idx,
+                                                          CtcOut* __restrict__ out) {
     const int seq = blockIdx.x;
     const int lane = threadIdx.x;
-    const int* ip = idx + (size_t)seq * T;
-    const float* pp = pmax + (size_t)seq * T;
-    int* op = out_idx + (size_t)seq * T;
+    const int2 sd = seqs[seq];
+    const int T = sd.y;
+    const int* ip = idx + (size_t)sd.x;
+    const float* pp = pmax + (size_t)sd.x;
+    int* op = out_idx + (size_t)sd.x;
     int len = 0, cnt = 0;
     float prod = 1.f;
     for (int t0 = 0; t0 < T; t0 += 64) {
@@ -79,14 +83,13 @@ __global__ void __launch_bounds__(64) ctc_collapse_kernel(const int* __restrict_
     }
 }
 
-hipError_t launch_ctc(const float* logits, int n, int T, int C, int cs, int* idx_tmp, float* pmax_tmp, int* out_idx, CtcOut* out,
-                      hipStream_t s) {
-    if (n <= 0 || T <= 0) return hipSuccess;
+hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,
+                      int* out_idx, CtcOut* out, hipStream_t s) {
+    if (nseq <= 0 || rows == 0) return hipSuccess;
     if (C > 128) return hipErrorInvalidValue;
-    const size_t rows = (size_t)n * T;
     const size_t blocks = (rows + 3) / 4;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
     hipLaunchKernelGGL(ctc_rows_kernel, dim3(grid), dim3(256), 0, s, logits, rows, C, cs, idx_tmp, pmax_tmp);
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, s, idx_tmp, pmax_tmp, n, T, out_idx, out);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(nseq), dim3(64), 0, s, idx_tmp, pmax_tmp, (const int2*)seqs_dev, out_idx, out);
     return hipGetLastError();
 }

@@ -78,10 +78,12 @@ hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, i
 hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, hipStream_t s);
 hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s);
 // BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
-hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, int n, int T, hipStream_t s);
+// tiles_dev: int4 per workgroup {first row, sequences (<=16), T, 0}; tensors are pooled over all buckets: [rows, C]
+hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s);
 void pack_lstm_whh(const float* whh_fwd /*[1024][256]*/, const float* whh_bwd, uint16_t* out);
 size_t lstm_whh_packed_elems();
 int lstm_xproj_channel(int dir, int gate, int unit);
 struct CtcOut { int len; int cnt; float prod; int pad; };
-hipError_t launch_ctc(const float* logits, int n, int T, int C, int cs, int* idx_tmp, float* pmax_tmp, int* out_idx, CtcOut* out,
-                      hipStream_t s);
+// seqs_dev: int2 per sequence {first row, T}; logits fp32 [rows, cs]; out_idx is row-indexed like the pool
+hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,
+                      int* out_idx, CtcOut* out, hipStream_t s);

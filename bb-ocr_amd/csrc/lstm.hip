@@ -43,13 +43,16 @@ int lstm_xproj_channel(int dir, int gate, int unit) {
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
 
+// tiles[b] = {first row of the tile's first sequence in the pooled [rows, C] tensors, sequences in the tile (<= 16), T, -};
+// sequence s of a tile owns rows [row0 + s*T, row0 + (s+1)*T).  Tiles of different buckets (different T) share one launch.
 __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
-                                                      uint16_t* __restrict__ out, int n, int T) {
+                                                      uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][32 * 16 * 16];   // [kgroup 32][seq 16] x 16 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y;
-    const int seq0 = blockIdx.x * 16;
+    const int4 tile = tiles[blockIdx.x];
+    const int row0 = tile.x, n = tile.y, T = tile.z;
     const int g = lane >> 4, u = lane & 15;
 
     for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 256) ((u32x4*)hbuf)[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -72,9 +75,9 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
         u32x4 xq[4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int s = seq0 + g * 4 + r;
+            const int s = g * 4 + r;
             if (s < n) {
-                const uint16_t* xp = xproj + ((size_t)s * T + t) * 2048 + xch;
+                const uint16_t* xp = xproj + ((size_t)row0 + (size_t)s * T + t) * 2048 + xch;
                 xq[r][0] = *(const u32x4*)(xp);
                 xq[r][1] = *(const u32x4*)(xp + 8);
             } else {
@@ -124,11 +127,11 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
         __syncthreads();
         // h_t -> out[seq][t][dir*256 + unit], 32 B per thread
         {
-            const int s = seq0 + wb_seq;
+            const int s = wb_seq;
             if (s < n) {
                 const u32x4 h0 = *(const u32x4*)(hn + ((wb_kg0) * 16 + wb_seq) * 16);
                 const u32x4 h1 = *(const u32x4*)(hn + ((wb_kg0 + 1) * 16 + wb_seq) * 16);
-                uint16_t* op = out + ((size_t)s * T + t) * 512 + dir * 256 + wb_kg0 * 8;
+                uint16_t* op = out + ((size_t)row0 + (size_t)s * T + t) * 512 + dir * 256 + wb_kg0 * 8;
                 *(u32x4*)(op) = h0;
                 *(u32x4*)(op + 8) = h1;
             }
@@ -137,8 +140,8 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
     }
 }
 
-hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, int n, int T, hipStream_t s) {
-    if (n <= 0 || T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lstm_kernel, dim3((n + 15) / 16, 2), dim3(256), 0, s, xproj, whh_pk, out, n, T);
+hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lstm_kernel, dim3(ntiles, 2), dim3(256), 0, s, xproj, whh_pk, out, (const int4*)tiles_dev);
     return hipGetLastError();
 }
