@@ -1142,6 +1142,47 @@ int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n) {
     return BBOCR_OK;
 }
 
+// ---------------------------------------------------------------------------------------- host-only geometry (no GPU needed)
+int bbocr_host_component_polys(const int* comps, const int* rowext, int n, int w, int h, double ratio, int* polys_out) {
+    if (!comps || !rowext || !polys_out || n < 0 || w <= 0 || h <= 0 || !(ratio > 0)) return BBOCR_ERR_ARG;
+    try {
+        for (int i = 0; i < n; ++i) {
+            const int* q = comps + (size_t)i * 7;
+            bbocr::Component cc{q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
+            float box[4][2];
+            bbocr::component_box(cc, rowext + (size_t)cc.row_off * 2, w, h, box);
+            bbocr::box_to_poly(box, 1.0 / ratio, 1.0 / ratio, polys_out + (size_t)i * 8);
+        }
+    } catch (...) {
+        return BBOCR_ERR_INTERNAL;
+    }
+    return BBOCR_OK;
+}
+
+int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr_boxlist** out) {
+    if ((!polys && n > 0) || n < 0 || !out) return BBOCR_ERR_ARG;
+    try {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        HostBoxes hb;
+        hb.polys.assign(1, {});
+        hb.hori.assign(1, {});
+        hb.freeb.assign(1, {});
+        for (int i = 0; i < n; ++i) {
+            std::array<int, 8> a;
+            memcpy(a.data(), polys + (size_t)i * 8, 32);
+            hb.polys[0].push_back(a);
+        }
+        bbocr::GroupParams gp{pp.slope_ths, pp.ycenter_ths, pp.height_ths, pp.width_ths, pp.add_margin, pp.min_size};
+        bbocr::group_text_box(hb.polys[0], gp, hb.hori[0], hb.freeb[0]);
+        *out = export_boxes(hb);
+    } catch (...) {
+        return BBOCR_ERR_INTERNAL;
+    }
+    return BBOCR_OK;
+}
+
 // ---------------------------------------------------------------------------------------- single-operator entry points
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, int KH,
                     int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out) {

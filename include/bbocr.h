@@ -136,6 +136,14 @@ int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n);
 int bbocr_set_profiling(bbocr_ctx* ctx, int on);
 int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches);
 
+/* ---- host-only halves of S4/S5 (no device work; callable without a GPU, used by the CPU test-suite) ----
+ * comps: [n][7] = root, left, top, right, bottom, area, row_off (heat-map coordinates); rowext: per component row the
+ * min/max x of TEXT pixels ([row_off + y - top][2], max < 0 = none) -- exactly what the CCL kernels emit.
+ * Writes n polygons [n][8] (craft_utils.getDetBoxes_core tail + adjustResultCoordinates + get_textbox). */
+int bbocr_host_component_polys(const int* comps, const int* rowext, int n, int w, int h, double ratio, int* polys_out);
+/* utils.group_text_box + Reader.detect's min_size filter on n polygons of one image */
+int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr_boxlist** out);
+
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
  * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout). */

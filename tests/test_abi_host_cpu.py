@@ -1,0 +1,228 @@
+"""CPU: the C-ABI library loads and exports what include/bbocr.h declares; host-side logic (box geometry in C++,
+Python Reader plumbing, weight loading) -- no GPU compute calls."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bb_ocr_amd import _lib
+
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from bb_ocr_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "bbocr.h")).read()
+    declared = set(re.findall(r"\b(bbocr_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/bbocr.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
+
+
+def test_default_params_mirror_readtext_defaults(lib):
+    from bb_ocr_amd import _lib
+
+    p = _lib.bbocr_params()
+    lib.bbocr_default_params(C.byref(p))
+    assert (p.text_threshold, p.low_text, p.link_threshold, p.canvas_size, p.mag_ratio) == (0.7, 0.4, 0.4, 2560, 1.0)
+    assert (p.slope_ths, p.ycenter_ths, p.height_ths, p.width_ths, p.add_margin, p.min_size) == (0.1, 0.5, 0.5, 0.5, 0.1, 20)
+    assert (p.contrast_ths, p.adjust_contrast) == (0.1, 0.5)
+
+
+@pytest.mark.parametrize("H,W,canvas", [(960, 1280, 2560), (3504, 2480, 2560), (971, 1014, 2560), (300, 500, 320), (64, 96, 2560)])
+def test_detect_dims_match_resize_aspect_ratio(lib, H, W, canvas):
+    from oracle import imgproc
+
+    v = [C.c_int() for _ in range(4)]
+    r = C.c_double()
+    assert lib.bbocr_detect_dims(H, W, canvas, 1.0, *[C.byref(x) for x in v], C.byref(r)) == 0
+    canvas_img, ratio, size_heatmap = imgproc.resize_aspect_ratio(np.zeros((H, W, 3), np.uint8), canvas, 1.0)
+    assert (v[0].value, v[1].value) == canvas_img.shape[:2]
+    assert (v[3].value, v[2].value) == size_heatmap and r.value == ratio
+    if (H, W) == (3504, 2480):
+        assert (v[0].value, v[1].value) == (2560, 1824)        # A4 @300 dpi
+
+
+def test_errors_are_status_codes_not_aborts(lib):
+    from bb_ocr_amd import _lib
+
+    assert lib.bbocr_detect_dims(0, 10, 2560, 1.0, None, None, None, None, None) == -1
+    assert lib.bbocr_stage_times(None, None, 0) == -1
+    assert lib.bbocr_last_error(None) == b"null context"
+    lib.bbocr_destroy(None)
+    lib.bbocr_free_result(None)
+    lib.bbocr_free_boxlist(None)
+    import torch
+
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        cfg = _lib.bbocr_config(device=0)
+        assert lib.bbocr_create(C.byref(cfg), C.byref(h)) == -2 and not h.value       # no HIP device: status, no crash
+
+
+def _components_from_heat(text, link, low_text=0.4, link_thr=0.4, text_thr=0.7):
+    """numpy stand-in for what ccl.hip emits: accepted components (raster order) + per-row text extremes."""
+    from oracle import boxes as obox
+
+    ts, ls = text > np.float32(low_text), link > np.float32(link_thr)
+    n, labels, stats = obox.connected_components_4((ts | ls).astype(np.uint8))
+    comps, rows = [], []
+    for k in range(1, n):
+        x, y, w, h, area = (int(v) for v in stats[k])
+        m = labels == k
+        if area < 10 or float(text[m].max()) < text_thr:
+            continue
+        off = len(rows) // 2
+        ys, xs = np.nonzero(m)
+        comps.append([int(ys.min() * text.shape[1] + xs[ys == ys.min()].min()), x, y, x + w - 1, y + h - 1, area, off])
+        for yy in range(y, y + h):
+            sel = m[yy] & ts[yy]
+            xs2 = np.nonzero(sel)[0]
+            rows += [int(xs2.min()), int(xs2.max())] if len(xs2) else [0x7FFFFFFF, -1]
+    return np.array(comps, dtype=np.int32).reshape(-1, 7), np.array(rows, dtype=np.int32)
+
+
+def test_host_box_geometry_matches_oracle(lib):
+    """boxpost.cpp (dilation of row extremes, hull, rotating calipers, boxPoints, diamond fix, int cast) == oracle."""
+    from bb_ocr_amd import _lib
+    from oracle import boxes as obox
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "oracle_boxes.npz"))
+    rng = np.random.default_rng(4)
+    cases = [(gold["text"], gold["link"])]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_pipeline as tp
+
+    for _ in range(3):
+        cases.append(tp._synth_heat(rng, 120, 200))
+    for text, link in cases:
+        for ratio in (1.0, 0.7306):
+            comps, rows = _components_from_heat(text, link)
+            det, _, _ = obox.get_det_boxes_core(text, link)
+            want = obox.boxes_to_int_polys(obox.adjust_result_coordinates(det, 1 / ratio, 1 / ratio))
+            assert len(want) == len(comps) > 0
+            out = np.zeros((len(comps), 8), np.int32)
+            rc = lib.bbocr_host_component_polys(comps.ctypes.data_as(C.POINTER(C.c_int)), rows.ctypes.data_as(C.POINTER(C.c_int)), len(comps),
+                                                text.shape[1], text.shape[0], ratio, out.ctypes.data_as(C.POINTER(C.c_int)))
+            assert rc == 0
+            assert np.array_equal(out, np.array(want, dtype=np.int32))
+            # grouping
+            for kw in ({}, {"add_margin": 0.2, "min_size": 5, "width_ths": 1.0}):
+                p = _lib.bbocr_params()
+                lib.bbocr_default_params(C.byref(p))
+                for k, v in kw.items():
+                    setattr(p, k, v)
+                bl = C.POINTER(_lib.bbocr_boxlist)()
+                assert lib.bbocr_host_group_boxes(out.ctypes.data_as(C.POINTER(C.c_int)), len(out), C.byref(p), C.byref(bl)) == 0
+                b = bl.contents
+                hori = [[b.hori[i * 4 + k] for k in range(4)] for i in range(b.hori_off[1])]
+                free = [[b.free_q[i * 8 + k] for k in range(8)] for i in range(b.free_off[1])]
+                lib.bbocr_free_boxlist(bl)
+                oh, of = obox.group_text_box(want, 0.1, 0.5, 0.5, kw.get("width_ths", 0.5), kw.get("add_margin", 0.1))
+                ms = kw.get("min_size", 20)
+                oh = [i for i in oh if max(i[1] - i[0], i[3] - i[2]) > ms]
+                of = [i for i in of if max(max(c[0] for c in i) - min(c[0] for c in i), max(c[1] for c in i) - min(c[1] for c in i)) > ms]
+                assert hori == [list(map(int, x)) for x in oh]
+                assert np.allclose(np.array(free).reshape(-1, 4, 2), np.array(of, dtype=np.float64).reshape(-1, 4, 2), rtol=0, atol=1e-9)
+
+
+def test_host_group_boxes_empty(lib):
+    from bb_ocr_amd import _lib
+
+    bl = C.POINTER(_lib.bbocr_boxlist)()
+    assert lib.bbocr_host_group_boxes(None, 0, None, C.byref(bl)) == 0
+    assert bl.contents.hori_off[1] == 0 and bl.contents.free_off[1] == 0
+    lib.bbocr_free_boxlist(bl)
+
+
+def test_reformat_input_mirrors_upstream_rules():
+    import bb_ocr_amd
+    from oracle import imgproc
+
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (12, 17, 3), dtype=np.uint8)
+    for inp in (rgb, rgb[..., 0], rgb[..., :1], np.dstack([rgb, rgb[..., :1]])):
+        a, g = bb_ocr_amd.reformat_input(inp)
+        ea, eg = imgproc.reformat_input(inp)
+        assert np.array_equal(a, ea) and np.array_equal(g, eg) and a.dtype == np.uint8 and a.shape[2] == 3
+    from PIL import Image
+    import io
+
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="PNG")
+    a, g = bb_ocr_amd.reformat_input(buf.getvalue())
+    assert np.array_equal(a, rgb) and np.array_equal(g, imgproc.gray_from_3ch(rgb, "bgr"))
+    with pytest.raises(ValueError):
+        bb_ocr_amd.reformat_input(3.14)
+
+
+def test_reader_requires_gpu_and_never_falls_back():
+    import torch
+
+    import bb_ocr_amd
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        bb_ocr_amd.Reader(["en"], gpu=True, weights="synthetic")
+    with pytest.raises(ValueError):
+        bb_ocr_amd.Reader(["fr"], weights="synthetic")
+
+
+def test_install_hook_registers_easyocr_module():
+    import bb_ocr_amd
+
+    prev = sys.modules.get("easyocr")
+    try:
+        m = bb_ocr_amd.install()
+        import easyocr
+
+        assert easyocr is m and easyocr.Reader is bb_ocr_amd.Reader
+    finally:
+        bb_ocr_amd.uninstall()
+        assert sys.modules.get("easyocr") is prev
+
+
+def test_synthetic_states_have_upstream_names_and_shapes(states):
+    import torch
+
+    from oracle import nets
+
+    cs, rs = states
+    nets.load_state_dict_any(nets.CRAFT(), {("module." + k): torch.from_numpy(v) for k, v in cs.items()})     # DataParallel prefix accepted
+    nets.load_state_dict_any(nets.CRNN(), {k: torch.from_numpy(v) for k, v in rs.items()})
+    n_conv = sum(v.size for k, v in cs.items() if k.endswith(".weight") and v.ndim == 4)
+    assert abs(n_conv - 20.75e6) < 0.05e6                       # 20.75 M conv parameters
+    assert rs["Prediction.weight"].shape == (97, 256)
+
+
+def test_weight_descriptor_table(states):
+    from bb_ocr_amd import weights
+
+    arr, keep = weights.to_descs(states[1])
+    names = {arr[i].name.decode() for i in range(len(arr))}
+    assert "SequenceModeling.0.rnn.weight_hh_l0_reverse" in names and not any(n.endswith("num_batches_tracked") for n in names)
+    i = [arr[k].name.decode() for k in range(len(arr))].index("FeatureExtraction.ConvNet.18.weight")
+    assert list(arr[i].shape) == [256, 256, 2, 2] and arr[i].ndim == 4
+
+
+def test_shard_range_partitions_exactly():
+    from bb_ocr_amd import dist
+
+    for n, w in [(512, 8), (128, 8), (10, 3), (2, 4), (0, 2)]:
+        parts = [dist.shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in parts]
+        assert max(sizes) - min(sizes) <= 1
+    assert dist.shard_range(512, 3, 8) == (192, 256)

@@ -207,3 +207,28 @@ def test_error_paths_raise(reader):
     with pytest.raises(NotImplementedError):
         reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), decoder="beamsearch")
     assert reader.readtext(np.full((64, 96, 3), 235, dtype=np.uint8)) == []      # blank page: no boxes, no error
+
+
+def test_hip_path_against_committed_golden(reader):
+    """Fixed numbers from tests/golden (written by the oracle): heat-map tolerance, boxes exact, logits tolerance."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_e2e.npz"))
+    img = np.repeat(g["page"][:, :, None], 3, 2)
+    heat, ratio = reader.heatmap_device(torch.from_numpy(img[None]).cuda())
+    got = heat[0].cpu().numpy()
+    assert ratio == float(g["ratio"])
+    assert np.abs(got[..., 0] - g["heat_text"].astype(np.float32)).max() <= HEAT_TOL
+    assert np.abs(got[..., 1] - g["heat_link"].astype(np.float32)).max() <= HEAT_TOL * 2
+    out = reader.readtext(img)
+    assert np.array_equal(np.array([b for b, _, _ in out], dtype=np.int64), g["boxes"])
+    x = torch.from_numpy(g["crnn_in"].astype(np.float32)).to(torch.bfloat16)
+    lg = torch.zeros((1, 31, 112), dtype=torch.float32, device="cuda")
+    reader._check(reader._lib.bbocr_crnn_logits(reader._h, C.c_void_p(x[:, 0].contiguous().cuda().data_ptr()), 1, 128, C.c_void_p(lg.data_ptr())))
+    ref = g["crnn_logits"]
+    rel = np.linalg.norm(lg.cpu().numpy()[:, :, :97] - ref) / np.linalg.norm(ref)
+    assert rel < 3e-2, rel
+    gb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_boxes.npz"))
+    heat2 = torch.from_numpy(np.stack([gb["text"], gb["link"]], -1)[None]).cuda()
+    hori, free, polys = reader.boxes_from_heatmap(heat2, 1.0)
+    assert np.array_equal(np.array(polys[0], dtype=np.int32), gb["polys"]) and np.array_equal(np.array(hori[0], dtype=np.int64).reshape(-1, 4), gb["hori"])

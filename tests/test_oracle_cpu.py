@@ -1,0 +1,173 @@
+"""CPU: the oracle against the committed golden vectors and against independent implementations (PIL, scipy)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def test_imgops_match_golden():
+    from oracle import imgproc
+
+    g = _npz("oracle_imgops.npz")
+    assert np.array_equal(imgproc.resize_linear_u8(g["src"], (91, 64)), g["lin_64x91"])
+    assert np.array_equal(imgproc.resize_linear_u8(g["src"], (26, 18)), g["lin_18x26"])
+    assert np.array_equal(imgproc.resize_linear_u8(g["src3"], (50, 40)), g["lin3_40x50"])
+    assert np.array_equal(imgproc.resize_linear_u8(g["src3"][:, :30], (15, 12)), g["area_12x15"])
+    assert np.array_equal(imgproc.pil_resize_bicubic_u8(g["tall"], (28, 64)), g["bicubic_28x64"])
+    assert np.array_equal(imgproc.gray_from_3ch(g["src3"], "bgr"), g["gray_bgr"])
+
+
+def test_resize_special_cases():
+    from oracle import imgproc
+
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    assert np.array_equal(imgproc.resize_linear_u8(a, (30, 20)), a)                      # same size: copy
+    half = imgproc.resize_linear_u8(a, (15, 10))                                        # exact 2x: INTER_AREA average
+    b = a.astype(int)
+    assert np.array_equal(half, ((b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    flat = np.full((7, 9), 200, np.uint8)
+    assert (imgproc.resize_linear_u8(flat, (33, 64)) == 200).all()                      # constant stays constant
+    up = imgproc.resize_linear_u8(a, (61, 64))
+    assert up.min() >= a.min() and up.max() <= a.max()
+
+
+@pytest.mark.parametrize("shape,dst", [((150, 64), (28, 64)), ((64, 64), (33, 64)), ((90, 64), (46, 64)), ((40, 100), (37, 17))])
+def test_pil_bicubic_restatement_matches_pillow(shape, dst):
+    from PIL import Image
+
+    from oracle import imgproc
+
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(0, 256, shape, dtype=np.uint8)
+    want = np.asarray(Image.fromarray(a, "L").resize(dst, Image.BICUBIC))
+    assert np.array_equal(imgproc.pil_resize_bicubic_u8(a, dst), want)
+
+
+def test_boxes_match_golden():
+    from oracle import boxes as obox
+
+    g = _npz("oracle_boxes.npz")
+    h, f, polys = obox.detect_from_heatmap(g["text"], g["link"], 1.0)
+    assert np.array_equal(np.array(polys, dtype=np.int32), g["polys"])
+    assert np.array_equal(np.array(h, dtype=np.int64).reshape(-1, 4), g["hori"])
+    assert np.allclose(np.array(f, dtype=np.float64).reshape(-1, 4, 2), g["free"], rtol=0, atol=1e-9)
+    assert len(polys) == 4 and len(f) >= 1     # the link patch joins the two top strokes into one component
+
+
+def test_connected_components_raster_order_and_stats():
+    from oracle import boxes as obox
+
+    m = np.zeros((6, 8), np.uint8)
+    m[0, 5:7] = 1          # first in raster order
+    m[1:4, 0:2] = 1
+    m[2, 2] = 1            # 4-connected to the block
+    m[3, 3] = 1            # diagonal only: separate component
+    n, labels, stats = obox.connected_components_4(m)
+    assert n == 4
+    assert labels[0, 5] == 1 and labels[1, 0] == 2 and labels[3, 3] == 3 and labels[2, 2] == 2
+    assert tuple(stats[2]) == (0, 1, 3, 3, 7)
+    assert tuple(stats[3]) == (3, 3, 1, 1, 1)
+
+
+def test_min_area_rect_axis_aligned_and_rotated():
+    from oracle import boxes as obox
+
+    ys, xs = np.mgrid[10:15, 20:41]
+    pts = np.stack([xs.ravel(), ys.ravel()], 1)
+    box = obox.component_box(pts)
+    assert np.array_equal(box, np.array([[20, 10], [40, 10], [40, 14], [20, 14]], np.float32))
+    # a 45-degree strip: the rectangle must contain every point and have (close to) the strip's area
+    t = np.arange(0, 30)
+    strip = np.concatenate([np.stack([t + k, t], 1) for k in range(4)])
+    rect = obox.min_area_rect(strip)
+    (cx, cy), (w, h), ang = rect
+    assert abs(min(w, h) - 3 / np.sqrt(2)) < 1e-3 and abs(max(w, h) - (29 * np.sqrt(2) + 3 / np.sqrt(2))) < 1e-3
+    bp = obox.box_points(rect)
+    assert np.allclose(bp.mean(0), [cx, cy], atol=1e-4)
+
+
+def test_group_text_box_lines_and_margins():
+    from oracle import boxes as obox
+
+    def quad(x0, y0, x1, y1):
+        return [x0, y0, x1, y0, x1, y1, x0, y1]
+
+    polys = [quad(10, 10, 60, 30), quad(68, 11, 130, 31), quad(300, 12, 360, 30),   # one line: first two merge, third too far
+             quad(10, 60, 80, 80),                                                   # own line
+             [200, 100, 260, 130, 250, 150, 190, 120]]                               # slanted -> free list
+    h, f = obox.group_text_box(polys, 0.1, 0.5, 0.5, 0.5, 0.1)
+    assert h == [[8, 132, 8, 33], [299, 361, 11, 31], [8, 82, 58, 82]]
+    assert len(f) == 1 and len(f[0]) == 4
+    assert obox.group_text_box([], 0.1, 0.5, 0.5, 0.5, 0.1) == ([], [])
+
+
+def test_ctc_matches_golden_and_edge_cases():
+    from oracle import recog
+
+    g = _npz("oracle_ctc.npz")
+    res = recog.predict_from_logits(g["logits"])
+    assert [r[0] for r in res] == list(g["texts"])
+    assert np.allclose([float(r[1]) for r in res], g["conf"], rtol=1e-6)
+    assert res[0][0] == "" and res[0][1] == 0.0                     # all blank
+    assert len(res[1][0]) >= 1
+    idx = np.array([0, 5, 5, 0, 5, 6, 6, 6, 0])
+    assert recog.decode_greedy(idx, [9]) == [recog.CHARACTER[5] * 2 + recog.CHARACTER[6]]
+    assert len(recog.CHARSET) == 96 and recog.CHARACTER[0] == "[blank]" and recog.CHARSET[43] == "€"
+
+
+def test_contrast_adjust_percentiles():
+    from oracle import recog
+
+    rng = np.random.default_rng(1)
+    img = rng.integers(100, 140, (64, 90), dtype=np.uint8)                 # low contrast -> stretched
+    out = recog.adjust_contrast_grey(img, target=0.5)
+    assert out.dtype == np.uint8 and out.std() > img.std() * 2
+    hi = np.where(rng.random((64, 90)) < 0.5, 5, 250).astype(np.uint8)     # already high contrast -> untouched
+    assert np.array_equal(recog.adjust_contrast_grey(hi, target=0.5), hi)
+
+
+def test_get_image_list_geometry():
+    from oracle import recog
+
+    grey = np.arange(100 * 200, dtype=np.uint32).reshape(100, 200).astype(np.uint8)
+    il, mw = recog.get_image_list([[-10, 120, 20, 52]], [], grey)      # clamped at x=0
+    assert il[0][0] == [[0, 20], [120, 20], [120, 52], [0, 52]] and il[0][1].shape == (64, 240) and mw == 256
+    il, mw = recog.get_image_list([[50, 70, 10, 90]], [], grey)        # tall box -> width 64, height 256
+    assert il[0][1].shape == (256, 64) and mw == 256
+    x = recog.align_collate_one(il[0][1], 64, mw)
+    assert x.shape == (1, 64, 256) and np.all(x[0, :, 16:] == x[0, :, 15:16])    # 16 content columns, edge-replicated pad
+    il, mw = recog.get_image_list([], [[[10.0, 10.0], [110.0, 20.0], [108.0, 44.0], [8.0, 34.0]]], grey)
+    assert il[0][1].shape[0] == 64 and mw % 64 == 0
+
+
+def test_network_shapes_and_end_to_end_golden(oracle_reader):
+    g = _npz("oracle_e2e.npz")
+    img = np.repeat(g["page"][:, :, None], 3, 2)
+    st, sl, ratio = oracle_reader.heatmap(img)
+    assert st.shape == (64, 128) and ratio == float(g["ratio"])
+    assert np.abs(st - g["heat_text"].astype(np.float32)).max() < 5e-3
+    assert np.abs(sl - g["heat_link"].astype(np.float32)).max() < 1e-2
+    out = oracle_reader.readtext(img)
+    assert np.array_equal(np.array([b for b, _, _ in out], dtype=np.int64), g["boxes"])
+    assert [t for _, t, _ in out] == list(g["texts"])
+    assert np.allclose([c for _, _, c in out], g["conf"], rtol=1e-4)
+    lg = oracle_reader._logits(g["crnn_in"].astype(np.float32))
+    assert lg.shape == (1, 31, 97)
+    assert np.abs(lg - g["crnn_logits"]).max() < 1e-3 * np.abs(g["crnn_logits"]).max()
+
+
+def test_designed_detector_finds_every_word(oracle_reader):
+    from bb_ocr_amd import synth
+    from oracle import boxes as obox
+
+    img, words = synth.page(5, width=384, height=192, lines=3, margin=24)
+    st, sl, ratio = oracle_reader.heatmap(img)
+    boxes, _, _ = obox.get_det_boxes_core(st, sl)
+    assert len(boxes) == len(words)
