@@ -163,9 +163,8 @@ static ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil) {
     ConvPlan p;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad_h = pad; p.pad_w = pad; p.dil = dil;
     p.Cin_pad = cdiv(Cin, 32) * 32;
-    if (Cout >= 256) { p.BN = 256; p.Cout_pad = cdiv(Cout, 256) * 256; }
-    else if (Cout > 64) { p.BN = 128; p.Cout_pad = 128; }
-    else { p.BN = 64; p.Cout_pad = 64; }
+    p.BN = conv_plan_bn(Cout);
+    p.Cout_pad = cdiv(Cout, p.BN) * p.BN;
     return p;
 }
 

@@ -14,16 +14,21 @@
 // (MF*16 pixels) x 64 couts.  Launch grid is XCD-remapped so the cout tiles of one pixel tile share an L2.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
-template <int WM, int WN, int MF, int PITER>
-__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(const ConvArgs a) {
+// 512-thread configs run one workgroup per CU (2 waves/SIMD inside it); 256-thread configs are built for TWO co-resident
+// workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
+template <int WM, int WN, int MF, int PITER, bool PIPE>
+__global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     constexpr int WBUF = BN * 64;          // bytes of one weight k-step slice (BN couts x 32 k x 2 B)
     constexpr int WPIECES = WBUF / 16;     // 16-B pieces per slice
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const wbuf = smem;                  // [2][WBUF]
-    unsigned char* const pbuf = smem + 2 * WBUF;       // [2][NP*64]
+    constexpr int WRING = PIPE ? 3 : 2;
+    unsigned char* const wbuf = smem;                  // [WRING][WBUF]
+    unsigned char* const pbuf = smem + WRING * WBUF;   // [2][NP*64]
     const int patch_bytes = a.NP * 64;
 
     const int tid = threadIdx.x;
@@ -60,8 +65,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(const ConvArgs 
         }
         src_pix[it] = sp;
     }
-    u32x4 pre[PITER];
-    auto load_patch = [&](int chunk) {
+    // The patch of one chunk is staged in NPART parts so that at most PH x 4 VGPRs are in flight at once.
+    constexpr int NPART = PITER > 4 ? 2 : 1, PH = PITER / NPART;
+    u32x4 pre[PH];
+    auto load_part = [&](int chunk, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
         const int c = chunk * 32;
         const bool s0 = c < a.C0;
         const uint16_t* src = s0 ? a.in0 : a.in1;
@@ -69,24 +77,61 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(const ConvArgs 
         const int cb = (s0 ? c : c - a.C0) + l_kg * 8;
         const bool relu = s0 ? a.relu_in0 : a.relu_in1;
 #pragma unroll
-        for (int it = 0; it < PITER; ++it) {
+        for (int i = 0; i < PH; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (src_pix[it] >= 0) {
-                v = *(const u32x4*)(src + (size_t)src_pix[it] * cs + cb);
+            if (src_pix[part * PH + i] >= 0) {
+                v = *(const u32x4*)(src + (size_t)src_pix[part * PH + i] * cs + cb);
                 if (relu) {
                     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
                 }
             }
-            pre[it] = v;
+            pre[i] = v;
         }
     };
-    auto store_patch = [&](int buf) {
+    auto store_part = [&](int buf, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
         unsigned char* pb = pbuf + buf * patch_bytes;
 #pragma unroll
-        for (int it = 0; it < PITER; ++it) {
-            const int wi = wave + it * NW;
-            if (wi < n_wi) *(u32x4*)(pb + (size_t)(l_kg * a.NP + wi * 16 + l_pix) * 16) = pre[it];
+        for (int i = 0; i < PH; ++i) {
+            const int wi = wave + (part * PH + i) * NW;
+            if (wi < n_wi) *(u32x4*)(pb + (size_t)(l_kg * a.NP + wi * 16 + l_pix) * 16) = pre[i];
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, NPART - 1>;
+    // staging schedule inside a chunk (taps 0 .. ntaps-1): part 0 loaded at tap 0, part 1 at tap t_mid; the last store
+    // happens at tap ntaps-2 so the pipelined schedule can prefetch the next chunk's fragments during the last tap
+    const int t_mid = (a.ntaps - 1) / 2;
+    auto stage_patch = [&](int chunk, int tap) {   // called once per k-step for the NEXT chunk (ntaps >= 3)
+        if (NPART == 1) {
+            if (tap == 0) load_part(chunk, P0{});
+            if (tap == a.ntaps - 2) store_part(chunk & 1, P0{});
+        } else {
+            if (tap == 0) load_part(chunk, P0{});
+            if (tap == (t_mid > 0 ? t_mid - 1 : 0)) store_part(chunk & 1, P0{});
+            if (tap == t_mid) load_part(chunk, P1{});
+            if (tap == a.ntaps - 2) store_part(chunk & 1, P1{});
+        }
+    };
+    auto stage_patch_load = [&](int chunk, int tap) {
+        if (tap == 0) load_part(chunk, P0{});
+        if (NPART == 2 && tap == t_mid) load_part(chunk, P1{});
+    };
+    auto stage_patch_store = [&](int chunk, int tap) {
+        if (NPART == 1) {
+            if (tap == a.ntaps - 2) store_part(chunk & 1, P0{});
+        } else {
+            if (tap == (t_mid > 0 ? t_mid - 1 : 0)) store_part(chunk & 1, P0{});
+            if (tap == a.ntaps - 2) store_part(chunk & 1, P1{});
+        }
+    };
+    auto stage_patch_now = [&](int chunk) {        // prologue: whole patch, synchronously
+        load_part(chunk, P0{});
+        store_part(chunk & 1, P0{});
+        if (NPART == 2) {
+            load_part(chunk, P1{});
+            store_part(chunk & 1, P1{});
         }
     };
     // ---- weight slice: LDS-DMA, LDS image == global image (fragment order), lane-linear
@@ -120,33 +165,122 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_patch(0);
-    issue_w(0, 0);
-    store_patch(0);
-    __syncthreads();
-
-    int ks = 0;
-    for (int c = 0; c < a.nchunks; ++c) {
-        const bool more = (c + 1 < a.nchunks);
-        if (more) load_patch(c + 1);
-        const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
-        int ky = 0, kx = 0;
-        for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
-            if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
-            const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
-            bf16x8 af[4];
+    if constexpr (!PIPE) {
+        // reference schedule: 2-deep weight ring, fragments read at the top of every k-step
+        issue_w(0, 0);
+        stage_patch_now(0);
+        __syncthreads();
+        int ks = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            const bool more = (c + 1 < a.nchunks);
+            if (more && a.ntaps < 3) load_part(c + 1, P0{});
+            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
+                if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
+                const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
+                bf16x8 af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
-            const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
+                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
+                // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
+                // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
+                bf16x8 bq[MF];
 #pragma unroll
-            for (int f = 0; f < MF; ++f) {
-                const bf16x8 bfr = *(const bf16x8*)(pb + frag_off[f]);
+                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bfr, acc[f][j], 0, 0, 0);
+                for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+                }
+                // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
+                if (more) {
+                    if (a.ntaps >= 3) stage_patch(c + 1, tap);
+                    else if (tap == a.ntaps - 1) store_part((c + 1) & 1, P0{});
+                }
+                __syncthreads();
+                if (++kx == a.KW) { kx = 0; ++ky; }
             }
-            if (more && tap == a.ntaps - 1) store_patch((c + 1) & 1);
-            __syncthreads();
-            if (++kx == a.KW) { kx = 0; ++ky; }
+        }
+    } else {
+        // counted-wait schedule: 3-deep weight ring.  Slice ks+2 is issued at k-step ks and only has to land by the
+        // end of k-step ks+1, and the next chunk's activation loads (issued first in their k-step, i.e. older than the
+        // weight slice behind them) stay in flight across one barrier too: the barrier waits with a COUNTED vmcnt
+        // that leaves exactly this k-step's VMEM operations outstanding, never vmcnt(0) inside the loop.
+        constexpr int WPT = (WPIECES + NT - 1) / NT;       // LDS-DMA instructions per issuing wave and slice
+        const bool w_wave = (wave * 64 < WPIECES);         // does this wave issue weight DMA at all (WM = 8: waves 0-3)
+        auto wait_barrier = [&](bool p_issued, bool w_issued) {
+            // lgkmcnt(0): this wave's patch ds_writes are done; vmcnt(N): everything older than this k-step's VMEM ops landed
+            const bool w = w_issued && w_wave;
+            if (p_issued) {
+                if (w) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PH + WPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PH) : "memory");
+            } else {
+                if (w) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        };
+        issue_w(0, 0);
+        if (nk > 1) issue_w(1, 1);
+        stage_patch_now(0);
+        __syncthreads();
+        int ks = 0, wslot = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            const bool more = (c + 1 < a.nchunks);
+            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
+                // activation loads first (older), then the weight slice two k-steps ahead (younger)
+                bool p_issued = false;
+                if (more) {
+                    if (a.ntaps >= 3) {
+                        if (tap == 0) { load_part(c + 1, P0{}); p_issued = true; }
+                        if (NPART == 2 && tap == t_mid) { load_part(c + 1, P1{}); p_issued = true; }
+                    } else if (tap == 0) {
+                        load_part(c + 1, P0{});
+                        p_issued = true;
+                    }
+                }
+                const bool w_issued = (ks + 2 < nk);
+                if (w_issued) issue_w(ks + 2, wslot == 0 ? 2 : wslot - 1);   // slot (ks+2)%3 == (ks-1)%3
+                const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
+                bf16x8 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
+                // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
+                // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
+                bf16x8 bq[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+                }
+                // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
+                bool p_stored = false;   // a store in this k-step makes hipcc wait for those loads itself
+                if (more) {
+                    if (a.ntaps >= 3) {
+                        if (NPART == 1) {
+                            if (tap == a.ntaps - 1) { store_part((c + 1) & 1, P0{}); p_stored = true; }
+                        } else {
+                            if (tap == t_mid - 1) { store_part((c + 1) & 1, P0{}); p_stored = true; }
+                            if (tap == a.ntaps - 1) { store_part((c + 1) & 1, P1{}); p_stored = true; }
+                        }
+                    } else if (tap == a.ntaps - 1) {
+                        store_part((c + 1) & 1, P0{});
+                        p_stored = true;
+                    }
+                }
+                wait_barrier(p_issued && !p_stored, w_issued);
+                if (++kx == a.KW) { kx = 0; ++ky; }
+                wslot = wslot == 2 ? 0 : wslot + 1;
+            }
         }
     }
 
@@ -220,9 +354,9 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
                 }
 }
 
-template <int WM, int WN, int MF, int PITER>
-static hipError_t launch_cfg(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
-    auto k = conv_mfma_kernel<WM, WN, MF, PITER>;
+template <int WM, int WN, int MF, int PITER, bool PIPE>
+static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
+    auto k = conv_mfma_kernel<WM, WN, MF, PITER, PIPE>;
     static size_t cur = 0;   // per-instantiation high-water mark of the opt-in dynamic LDS size
     if (smem > cur) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -233,14 +367,42 @@ static hipError_t launch_cfg(const ConvArgs& a, size_t smem, int grid, hipStream
     return hipGetLastError();
 }
 
+static bool conv_pipelined() {   // BBOCR_CONV_PIPE=1 selects the counted-vmcnt 3-deep-ring schedule (A/B runs)
+    static const bool v = [] { const char* e = getenv("BBOCR_CONV_PIPE"); return e && e[0] == '1'; }();
+    return v;
+}
+
+#define NP_TWO_PART(P) ((P) > 4)
+template <int WM, int WN, int MF, int PITER>
+static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
+    const bool pipe = conv_pipelined() && !NP_TWO_PART(PITER);   // the two-part staging variant of this schedule spills
+    const size_t smem = (size_t)(pipe ? 3 : 2) * WN * 64 * 64 + (size_t)2 * a.NP * 64;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    return pipe ? launch_one<WM, WN, MF, PITER, true>(a, smem, grid, s) : launch_one<WM, WN, MF, PITER, false>(a, smem, grid, s);
+}
+
+static bool conv_small_wg() {   // BBOCR_CONV_WG=512 selects the original one-workgroup-per-CU configurations (A/B runs)
+    static const bool v = [] { const char* e = getenv("BBOCR_CONV_WG"); return !(e && atoi(e) == 512); }();
+    return v;
+}
+
+int conv_plan_bn(int Cout) {
+    if (conv_small_wg()) return Cout > 64 ? 128 : 64;
+    return Cout >= 256 ? 256 : (Cout > 64 ? 128 : 64);
+}
+
 hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const int BN = p.BN;
-    const int BM = (BN == 256) ? 256 : 512;
+    const bool small = conv_small_wg();
+    const int NWV = small ? 4 : 8;                                  // waves per workgroup
+    const int BM = small ? 256 : ((BN == 256) ? 256 : 512);
     a.KH = p.KH; a.KW = p.KW; a.pad_h = p.pad_h; a.pad_w = p.pad_w; a.dil = p.dil;
     a.OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil;
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
+    const int ring = 2;
+    const int max_piter = small ? 16 : 8;
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
     {
         long long best = -1;
@@ -248,7 +410,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             const int tw = BM / th;
             const int ph = th + (p.KH - 1) * p.dil, pw = tw + (p.KW - 1) * p.dil;
             const int np = cdiv(ph * pw, 16) * 16;
-            if (cdiv(np / 16, 8) > 8) continue;
+            if (cdiv(np / 16, NWV) > max_piter || (size_t)ring * BN * 64 + (size_t)2 * np * 64 > 160 * 1024) continue;
             const long long tiles = (long long)cdiv(a.OH, th) * cdiv(a.OW, tw);
             const long long cost = tiles * ((long long)BM * a.ntaps + 2LL * np);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = np; }
@@ -263,15 +425,17 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     if ((a.in0_cs & 7) || (a.C1 && (a.in1_cs & 7)) || (a.out_cs & (a.out_f32 ? 3 : 7)) || (a.cout_store & 15)) return hipErrorInvalidValue;
     a.wpk = p.d_w;
     a.bias = p.d_b;
-    const size_t smem = (size_t)2 * BN * 64 + (size_t)2 * a.NP * 64;
-    if (smem > 160 * 1024) return hipErrorInvalidValue;
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
-    const int piter = cdiv(a.NP / 16, 8);
-    if (piter > 8) return hipErrorInvalidValue;
-    if (BN == 256) return piter <= 4 ? launch_cfg<2, 4, 8, 4>(a, smem, grid, s) : launch_cfg<2, 4, 8, 8>(a, smem, grid, s);
-    if (BN == 128) return piter <= 4 ? launch_cfg<4, 2, 8, 4>(a, smem, grid, s) : launch_cfg<4, 2, 8, 8>(a, smem, grid, s);
-    if (BN == 64) return piter <= 4 ? launch_cfg<8, 1, 4, 4>(a, smem, grid, s) : launch_cfg<8, 1, 4, 8>(a, smem, grid, s);
+    const int piter = cdiv(a.NP / 16, NWV);
+    if (small) {
+        if (BN == 128) return piter <= 4 ? launch_cfg<2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<2, 2, 8, 8>(a, grid, s) : launch_cfg<2, 2, 8, 16>(a, grid, s));
+        if (BN == 64) return piter <= 4 ? launch_cfg<4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<4, 1, 4, 8>(a, grid, s) : launch_cfg<4, 1, 4, 16>(a, grid, s));
+        return hipErrorInvalidValue;
+    }
+    if (BN == 256) return piter <= 4 ? launch_cfg<2, 4, 8, 4>(a, grid, s) : launch_cfg<2, 4, 8, 8>(a, grid, s);
+    if (BN == 128) return piter <= 4 ? launch_cfg<4, 2, 8, 4>(a, grid, s) : launch_cfg<4, 2, 8, 8>(a, grid, s);
+    if (BN == 64) return piter <= 4 ? launch_cfg<8, 1, 4, 4>(a, grid, s) : launch_cfg<8, 1, 4, 8>(a, grid, s);
     return hipErrorInvalidValue;
 }

@@ -30,6 +30,7 @@ struct ConvPlan {      // host-side description of one packed conv layer
     float* d_b = nullptr;      // device bias [Cout_pad]
 };
 
+int conv_plan_bn(int Cout);   // cout tile (64/128/256) of the launch configuration used for a layer
 size_t conv_packed_elems(const ConvPlan& p);
 // w: fp32 [Cout][Cin][KH][KW] already BN-folded; out: bf16 bits, layout [ntile][chunk][tap][frag][lane][8]
 void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out);

@@ -60,6 +60,10 @@ def _conv_case(reader, N, H, W, Cin, Cout, K, pad, dil, relu_in, relu_out, out_f
     (1, 9, 33, 32, 16, 3, 1, 1, 0, 1, 0),       # Cout 16
     (1, 5, 40, 256, 97, 1, 0, 1, 0, 0, 1),      # prediction layer, fp32 out, Cout 97 -> 112
     (1, 30, 45, 256, 2048, 1, 0, 1, 0, 0, 0),   # LSTM input projection shape
+    (1, 18, 21, 32, 64, 1, 0, 1, 0, 0, 0),      # single k-step (1x1, one chunk)
+    (1, 18, 21, 64, 256, 1, 0, 1, 1, 1, 0),     # two k-steps
+    (1, 33, 47, 128, 128, 3, 1, 1, 0, 1, 0),    # BN=128, 4 chunks, two-part patch staging
+    (3, 40, 52, 512, 512, 3, 1, 1, 0, 1, 0),    # long K loop (144 k-steps), batch 3
 ])
 def test_conv_mfma_vs_fp64(reader, cfg):
     _conv_case(reader, *cfg)

@@ -229,6 +229,6 @@ def test_hip_path_against_committed_golden(reader):
     rel = np.linalg.norm(lg.cpu().numpy()[:, :, :97] - ref) / np.linalg.norm(ref)
     assert rel < 3e-2, rel
     gb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_boxes.npz"))
-    heat2 = torch.from_numpy(np.stack([gb["text"], gb["link"]], -1)[None]).cuda()
+    heat2 = torch.from_numpy(np.stack([gb["text"], gb["link"]], -1)[None].astype(np.float32)).cuda()
     hori, free, polys = reader.boxes_from_heatmap(heat2, 1.0)
     assert np.array_equal(np.array(polys[0], dtype=np.int32), gb["polys"]) and np.array_equal(np.array(hori[0], dtype=np.int64).reshape(-1, 4), gb["hori"])
