@@ -435,12 +435,19 @@ static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, c
     if (B <= 0 || H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad page batch shape");
     const DetDims d = det_dims(H, W, p.canvas_size, p.mag_ratio);
     if (d.th <= 0 || d.tw <= 0) fail(BBOCR_ERR_ARG, "page collapses to zero size");
-    const int sb = c->cfg.det_sub_batch > 0 ? c->cfg.det_sub_batch : 8;
+    // pages per detector pass: as many as fit a 40 GB activation arena (sized by a dry run on one page), at most 32
+    int sb = c->cfg.det_sub_batch;
+    if (sb <= 0) {
+        c->arena.begin(true);
+        craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
+        const size_t per_page = std::max<size_t>(c->arena.off, 1);
+        sb = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)40 << 30) / per_page));
+    }
+    sb = std::min(sb, B);
     const bool need_resize = (d.th != H || d.tw != W);
-    if (need_resize) c->resized.ensure((size_t)std::min(sb, B) * d.th * d.tw * 3);
-    const int nb0 = std::min(sb, B);
+    if (need_resize) c->resized.ensure((size_t)sb * d.th * d.tw * 3);
     c->arena.begin(true);
-    craft_forward(c, nullptr, nb0, d.th, d.tw, d.H32, d.W32, nullptr);
+    craft_forward(c, nullptr, sb, d.th, d.tw, d.H32, d.W32, nullptr);
     c->arena.buf.ensure(c->arena.off);
     for (int b0 = 0; b0 < B; b0 += sb) {
         const int nb = std::min(sb, B - b0);

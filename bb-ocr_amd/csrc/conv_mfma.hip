@@ -205,82 +205,62 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
             }
         }
     } else {
-        // counted-wait schedule: 3-deep weight ring.  Slice ks+2 is issued at k-step ks and only has to land by the
-        // end of k-step ks+1, and the next chunk's activation loads (issued first in their k-step, i.e. older than the
-        // weight slice behind them) stay in flight across one barrier too: the barrier waits with a COUNTED vmcnt
-        // that leaves exactly this k-step's VMEM operations outstanding, never vmcnt(0) inside the loop.
-        constexpr int WPT = (WPIECES + NT - 1) / NT;       // LDS-DMA instructions per issuing wave and slice
-        const bool w_wave = (wave * 64 < WPIECES);         // does this wave issue weight DMA at all (WM = 8: waves 0-3)
-        auto wait_barrier = [&](bool p_issued, bool w_issued) {
-            // lgkmcnt(0): this wave's patch ds_writes are done; vmcnt(N): everything older than this k-step's VMEM ops landed
-            const bool w = w_issued && w_wave;
-            if (p_issued) {
-                if (w) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PH + WPT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PH) : "memory");
-            } else {
-                if (w) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-        };
+        // software-pipelined schedule (taps >= 3): 3-deep weight ring; each k-step is two halves of 2*MF MFMAs.  While
+        // the first half issues, the second half's activation fragments are in flight; while the second half issues, the
+        // NEXT k-step's weight fragments and first-half activation fragments are in flight.  A wave therefore leaves the
+        // barrier with operands in registers and never waits on LDS latency in front of an MFMA group.  The next chunk's
+        // patch must be visible one k-step earlier than in the reference schedule (stored by tap ntaps-2).
+        constexpr int HF = MF / 2;
         issue_w(0, 0);
         if (nk > 1) issue_w(1, 1);
         stage_patch_now(0);
         __syncthreads();
-        int ks = 0, wslot = 0;
-        for (int c = 0; c < a.nchunks; ++c) {
+        bf16x8 af[4], an[4], bq[MF];
+        {
+            const unsigned char* wb = wbuf + lane_w_off;
+            const unsigned char* pb = pbuf + lane_patch_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+#pragma unroll
+            for (int f = 0; f < HF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+        }
+        int c = 0, tap = 0, ky = 0, kx = 0, wslot = 0;
+        for (int ks = 0; ks < nk; ++ks) {
             const bool more = (c + 1 < a.nchunks);
-            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
-            int ky = 0, kx = 0;
-            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
-                // activation loads first (older), then the weight slice two k-steps ahead (younger)
-                bool p_issued = false;
-                if (more) {
-                    if (a.ntaps >= 3) {
-                        if (tap == 0) { load_part(c + 1, P0{}); p_issued = true; }
-                        if (NPART == 2 && tap == t_mid) { load_part(c + 1, P1{}); p_issued = true; }
-                    } else if (tap == 0) {
-                        load_part(c + 1, P0{});
-                        p_issued = true;
-                    }
-                }
-                const bool w_issued = (ks + 2 < nk);
-                if (w_issued) issue_w(ks + 2, wslot == 0 ? 2 : wslot - 1);   // slot (ks+2)%3 == (ks-1)%3
-                const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
-                bf16x8 af[4];
+            if (more) stage_patch_load(c + 1, tap);
+            if (ks + 2 < nk) issue_w(ks + 2, wslot == 0 ? 2 : wslot - 1);   // slot (ks+2)%3 == (ks-1)%3
+            int c1 = c, tap1 = tap + 1, ky1 = ky, kx1 = kx + 1;
+            if (kx1 == a.KW) { kx1 = 0; ++ky1; }
+            if (tap1 == a.ntaps) { tap1 = 0; ky1 = 0; kx1 = 0; ++c1; }
+            const bool has_next = (ks + 1 < nk);
+            const int wslot1 = wslot == 2 ? 0 : wslot + 1;
+            const unsigned char* pb0 = pbuf + (c & 1) * patch_bytes + lane_patch_off + ((ky * a.PW + kx) * a.dil) * 16;
+            // the last k-step re-reads its own operands instead of branching around the prefetch
+            const unsigned char* wb1 = wbuf + (has_next ? wslot1 : wslot) * WBUF + lane_w_off;
+            const unsigned char* pb1 = has_next ? pbuf + (c1 & 1) * patch_bytes + lane_patch_off + ((ky1 * a.PW + kx1) * a.dil) * 16 : pb0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
-                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
-                // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
-                // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
-                bf16x8 bq[MF];
+            for (int f = HF; f < MF; ++f) bq[f] = *(const bf16x8*)(pb0 + frag_off[f]);
 #pragma unroll
-                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+            for (int f = 0; f < HF; ++f)
 #pragma unroll
-                for (int f = 0; f < MF; ++f) {
+                for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-                }
-                // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
-                bool p_stored = false;   // a store in this k-step makes hipcc wait for those loads itself
-                if (more) {
-                    if (a.ntaps >= 3) {
-                        if (NPART == 1) {
-                            if (tap == a.ntaps - 1) { store_part((c + 1) & 1, P0{}); p_stored = true; }
-                        } else {
-                            if (tap == t_mid - 1) { store_part((c + 1) & 1, P0{}); p_stored = true; }
-                            if (tap == a.ntaps - 1) { store_part((c + 1) & 1, P1{}); p_stored = true; }
-                        }
-                    } else if (tap == a.ntaps - 1) {
-                        store_part((c + 1) & 1, P0{});
-                        p_stored = true;
-                    }
-                }
-                wait_barrier(p_issued && !p_stored, w_issued);
-                if (++kx == a.KW) { kx = 0; ++ky; }
-                wslot = wslot == 2 ? 0 : wslot + 1;
-            }
+            for (int j = 0; j < 4; ++j) an[j] = *(const bf16x8*)(wb1 + j * 1024);
+#pragma unroll
+            for (int f = 0; f < HF; ++f) bq[f] = *(const bf16x8*)(pb1 + frag_off[f]);
+#pragma unroll
+            for (int f = HF; f < MF; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, HF, 0);          // second-half activation reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * HF, 0);      // first-half MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + HF, 0);      // next k-step: weights + first-half activations
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * HF, 0);      // second-half MFMAs
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = an[j];
+            if (more) stage_patch_store(c + 1, tap);
+            __syncthreads();
+            c = c1; tap = tap1; ky = ky1; kx = kx1; wslot = wslot1;
         }
     }
 
@@ -367,7 +347,7 @@ static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream
     return hipGetLastError();
 }
 
-static bool conv_pipelined() {   // BBOCR_CONV_PIPE=1 selects the counted-vmcnt 3-deep-ring schedule (A/B runs)
+static bool conv_pipelined() {   // BBOCR_CONV_PIPE=1 selects the software-pipelined schedule (A/B runs; measured 6 % slower)
     static const bool v = [] { const char* e = getenv("BBOCR_CONV_PIPE"); return e && e[0] == '1'; }();
     return v;
 }
@@ -375,7 +355,7 @@ static bool conv_pipelined() {   // BBOCR_CONV_PIPE=1 selects the counted-vmcnt 
 #define NP_TWO_PART(P) ((P) > 4)
 template <int WM, int WN, int MF, int PITER>
 static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
-    const bool pipe = conv_pipelined() && !NP_TWO_PART(PITER);   // the two-part staging variant of this schedule spills
+    const bool pipe = conv_pipelined() && a.ntaps >= 3 && PITER <= 8;
     const size_t smem = (size_t)(pipe ? 3 : 2) * WN * 64 * 64 + (size_t)2 * a.NP * 64;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     return pipe ? launch_one<WM, WN, MF, PITER, true>(a, smem, grid, s) : launch_one<WM, WN, MF, PITER, false>(a, smem, grid, s);
@@ -401,7 +381,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
-    const int ring = 2;
+    const int ring = conv_pipelined() ? 3 : 2;
     const int max_piter = small ? 16 : 8;
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
     {
