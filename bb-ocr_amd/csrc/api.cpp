@@ -4,12 +4,14 @@
 #include "../../include/bbocr.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -503,7 +505,8 @@ static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, dou
     hb.polys.assign(B, {});
     hb.hori.assign(B, {});
     hb.freeb.assign(B, {});
-    for (int b = 0; b < B; ++b) {
+    // pages are independent: fan the O(#components) geometry out over a few host threads
+    auto do_page = [&](int b) {
         std::sort(comps[b].begin(), comps[b].end(), [](const CclOut& x, const CclOut& y) { return x.root < y.root; });
         for (const CclOut& co : comps[b]) {
             bbocr::Component cc{co.root, co.left, co.top, co.right, co.bottom, co.area, co.row_off};
@@ -514,6 +517,26 @@ static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, dou
             hb.polys[b].push_back(poly);
         }
         bbocr::group_text_box(hb.polys[b], gp, hb.hori[b], hb.freeb[b]);
+    };
+    const int nthr = std::max(1, std::min({B, 16, (int)std::thread::hardware_concurrency()}));
+    if (nthr <= 1) {
+        for (int b = 0; b < B; ++b) do_page(b);
+    } else {
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        std::exception_ptr err;
+        std::mutex err_mu;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back([&] {
+                try {
+                    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) do_page(b);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    err = std::current_exception();
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (err) std::rethrow_exception(err);
     }
     c->times[2] += (float)ms_since(t0);
 }

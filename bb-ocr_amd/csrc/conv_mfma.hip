@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
         src_pix[it] = sp;
     }
     // The patch of one chunk is staged in NPART parts so that at most PH x 4 VGPRs are in flight at once.
-    constexpr int NPART = PITER > 4 ? 2 : 1, PH = PITER / NPART;
+    constexpr int NPART = (PITER + 3) / 4, PH = PITER / NPART;   // PITER 4/8/16 -> 1/2/4 parts of 4 wave-instructions
     u32x4 pre[PH];
     auto load_part = [&](int chunk, auto part_c) {
         constexpr int part = decltype(part_c)::value;
@@ -99,40 +99,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
         }
     };
     using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, NPART - 1>;
-    // staging schedule inside a chunk (taps 0 .. ntaps-1): part 0 loaded at tap 0, part 1 at tap t_mid; the last store
-    // happens at tap ntaps-2 so the pipelined schedule can prefetch the next chunk's fragments during the last tap
-    const int t_mid = (a.ntaps - 1) / 2;
-    auto stage_patch = [&](int chunk, int tap) {   // called once per k-step for the NEXT chunk (ntaps >= 3)
-        if (NPART == 1) {
-            if (tap == 0) load_part(chunk, P0{});
-            if (tap == a.ntaps - 2) store_part(chunk & 1, P0{});
-        } else {
-            if (tap == 0) load_part(chunk, P0{});
-            if (tap == (t_mid > 0 ? t_mid - 1 : 0)) store_part(chunk & 1, P0{});
-            if (tap == t_mid) load_part(chunk, P1{});
-            if (tap == a.ntaps - 2) store_part(chunk & 1, P1{});
-        }
-    };
+    // staging schedule inside a chunk with >= 3 taps: part i of the NEXT chunk is loaded at tap i*S and stored at tap
+    // i*S + S - 1, S = (ntaps-1)/NPART, so the last store lands at tap <= ntaps-2 (the pipelined schedule reads the next
+    // chunk's first fragments during the last tap) and at most one part (PH x 4 VGPRs) is in flight.
+    const int S = (a.ntaps - 1) / NPART;
     auto stage_patch_load = [&](int chunk, int tap) {
         if (tap == 0) load_part(chunk, P0{});
-        if (NPART == 2 && tap == t_mid) load_part(chunk, P1{});
+        if constexpr (NPART > 1) { if (tap == S) load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { if (tap == 2 * S) load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { if (tap == 3 * S) load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
     };
     auto stage_patch_store = [&](int chunk, int tap) {
-        if (NPART == 1) {
-            if (tap == a.ntaps - 2) store_part(chunk & 1, P0{});
-        } else {
-            if (tap == (t_mid > 0 ? t_mid - 1 : 0)) store_part(chunk & 1, P0{});
-            if (tap == a.ntaps - 2) store_part(chunk & 1, P1{});
-        }
+        if (tap == S - 1) store_part(chunk & 1, P0{});
+        if constexpr (NPART > 1) { if (tap == 2 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { if (tap == 3 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { if (tap == 4 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
     };
     auto stage_patch_now = [&](int chunk) {        // prologue: whole patch, synchronously
         load_part(chunk, P0{});
         store_part(chunk & 1, P0{});
-        if (NPART == 2) {
-            load_part(chunk, P1{});
-            store_part(chunk & 1, P1{});
-        }
+        if constexpr (NPART > 1) { load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
     };
     // ---- weight slice: LDS-DMA, LDS image == global image (fragment order), lane-linear
     const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
@@ -177,6 +165,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
             const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
             int ky = 0, kx = 0;
             for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
+                if (more && a.ntaps >= 3) stage_patch_load(c + 1, tap);
                 if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
                 const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
                 bf16x8 af[4];
@@ -197,7 +186,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
                 if (more) {
-                    if (a.ntaps >= 3) stage_patch(c + 1, tap);
+                    if (a.ntaps >= 3) stage_patch_store(c + 1, tap);
                     else if (tap == a.ntaps - 1) store_part((c + 1) & 1, P0{});
                 }
                 __syncthreads();
@@ -390,7 +379,9 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             const int tw = BM / th;
             const int ph = th + (p.KH - 1) * p.dil, pw = tw + (p.KW - 1) * p.dil;
             const int np = cdiv(ph * pw, 16) * 16;
-            if (cdiv(np / 16, NWV) > max_piter || (size_t)ring * BN * 64 + (size_t)2 * np * 64 > 160 * 1024) continue;
+            const int pit = cdiv(np / 16, NWV), pit_r = pit <= 4 ? 4 : (pit <= 8 ? 8 : 16), nparts = pit_r / 4;
+            if (pit > max_piter || (size_t)ring * BN * 64 + (size_t)2 * np * 64 > 160 * 1024) continue;
+            if (a.ntaps >= 3 ? (a.ntaps - 1) / nparts < 1 : nparts > 1) continue;
             const long long tiles = (long long)cdiv(a.OH, th) * cdiv(a.OW, tw);
             const long long cost = tiles * ((long long)BM * a.ntaps + 2LL * np);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = np; }

@@ -45,9 +45,16 @@ __device__ __forceinline__ float tanh_f(float x) { return 2.f / (1.f + __expf(-2
 
 // tiles[b] = {first row of the tile's first sequence in the pooled [rows, C] tensors, sequences in the tile (<= 16), T, -};
 // sequence s of a tile owns rows [row0 + s*T, row0 + (s+1)*T).  Tiles of different buckets (different T) share one launch.
+// W_hh residency: of the 128 weight fragments (1 KiB each) a wave multiplies per step, the first LSTM_NR stay in its
+// registers for all T steps (one wave per SIMD owns the whole 512-entry file), the next LSTM_NL in LDS, and only the
+// rest is re-streamed from L2 every step (512 KiB -> 128 KiB per workgroup and step).
+#define LSTM_NR 64
+#define LSTM_NL 32
 __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
                                                       uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][32 * 16 * 16];   // [kgroup 32][seq 16] x 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
+    unsigned char (*hbuf)[32 * 16 * 16] = (unsigned char (*)[32 * 16 * 16])lstm_smem;   // [2][kgroup 32][seq 16] x 16 B
+    unsigned char* const wlds = lstm_smem + 2 * 32 * 16 * 16;                             // [wave 4][LSTM_NL][lane 64] x 16 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y;
@@ -55,13 +62,20 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
     const int row0 = tile.x, n = tile.y, T = tile.z;
     const int g = lane >> 4, u = lane & 15;
 
-    for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 256) ((u32x4*)hbuf)[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 256) ((u32x4*)lstm_smem)[i] = (u32x4){0u, 0u, 0u, 0u};
     float c[4][4];   // [u16][r]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
     const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
+    // fragment fi = kk*16 + u16*4 + gate, in MFMA issue order
+    bf16x8 wreg[LSTM_NR];
+#pragma unroll
+    for (int i = 0; i < LSTM_NR; ++i) wreg[i] = wv0[(size_t)i * 64];
+    bf16x8* const wl = (bf16x8*)(wlds + (size_t)wave * LSTM_NL * 1024) + lane;
+#pragma unroll 4
+    for (int i = 0; i < LSTM_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(LSTM_NR + i) * 64];
     // xproj element offset of this lane's 16 contiguous channels
     const int xch = dir * 1024 + (wave * 16 + u) * 16;
     // coalesced h write-back: thread -> (seq, 16-B chunk of the 256 units)
@@ -91,8 +105,8 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned char* hb = hbuf[cur];
-        // W_hh is step-invariant; hiding the pointer keeps hipcc from hoisting 128 fragment loads out of the time loop
-        // (512 VGPRs + spills).  The fragments stream from L2 every step instead.
+        // hiding the pointer keeps hipcc from hoisting the STREAMED fragment loads out of the time loop as well
+        // (they would need another 128 VGPRs and spill).
         const bf16x8* wv = wv0;
         asm volatile("" : "+v"(wv));
 #pragma unroll
@@ -102,7 +116,11 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const bf16x8 bfr = wv[(size_t)((kk * 4 + a) * 4 + q) * 64];
+                    const int fi = (kk * 4 + a) * 4 + q;
+                    bf16x8 bfr;
+                    if (fi < LSTM_NR) bfr = wreg[fi < LSTM_NR ? fi : 0];
+                    else if (fi < LSTM_NR + LSTM_NL) bfr = wl[(size_t)(fi - LSTM_NR) * 64];
+                    else bfr = wv[(size_t)fi * 64];
                     acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[a][q], 0, 0, 0);
                 }
         }
@@ -142,6 +160,13 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
 
 hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lstm_kernel, dim3(ntiles, 2), dim3(256), 0, s, xproj, whh_pk, out, (const int4*)tiles_dev);
+    const size_t smem = 2 * 32 * 16 * 16 + (size_t)4 * LSTM_NL * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_kernel, dim3(ntiles, 2), dim3(256), smem, s, xproj, whh_pk, out, (const int4*)tiles_dev);
     return hipGetLastError();
 }
