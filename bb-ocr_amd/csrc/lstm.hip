@@ -11,17 +11,18 @@
 // c stays in fp32 registers for all T steps; h crosses LDS as bf16 (it is the next step's A operand).
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
 
-// out layout: [dir][wave 4][kk 8][u16 4][gate 4][lane 64][8]
+// out layout: [dir][wave 4][u16 4][kk 8][gate 4][lane 64][8]  (= MFMA issue order inside a wave)
 void pack_lstm_whh(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
     size_t o = 0;
     for (int d = 0; d < 2; ++d) {
         const float* W = d ? whh_bwd : whh_fwd;
         for (int w = 0; w < 4; ++w)
-            for (int kk = 0; kk < 8; ++kk)
-                for (int u16 = 0; u16 < 4; ++u16)
+            for (int u16 = 0; u16 < 4; ++u16)
+                for (int kk = 0; kk < 8; ++kk)
                     for (int gate = 0; gate < 4; ++gate)
                         for (int l = 0; l < 64; ++l) {
                             const int unit = w * 64 + u16 * 16 + (l & 15);
@@ -40,8 +41,9 @@ int lstm_xproj_channel(int dir, int gate, int unit) {
     return dir * 1024 + (((unit >> 6) * 16 + (unit & 15)) * 16) + ((unit >> 4) & 3) * 4 + gate;
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): 2 transcendental issues per non-linearity instead of an IEEE division sequence
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.442695041f)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390082f)); }
 
 // tiles[b] = {first row of the tile's first sequence in the pooled [rows, C] tensors, sequences in the tile (<= 16), T, -};
 // sequence s of a tile owns rows [row0 + s*T, row0 + (s+1)*T).  Tiles of different buckets (different T) share one launch.
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
     const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
-    // fragment fi = kk*16 + u16*4 + gate, in MFMA issue order
+    // fragment fi = (u16*8 + kk)*4 + gate, in MFMA issue order
     bf16x8 wreg[LSTM_NR];
 #pragma unroll
     for (int i = 0; i < LSTM_NR; ++i) wreg[i] = wv0[(size_t)i * 64];
@@ -82,15 +84,12 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
     const int wb_seq = tid >> 4, wb_kg0 = (tid & 15) * 2;
     __syncthreads();
 
-    int cur = 0;
-    for (int step = 0; step < T; ++step) {
+    auto load_x = [&](int step, u32x4 (&xq)[4][2]) {
         const int t = dir ? (T - 1 - step) : step;
-        // gate pre-activations from the input projection (bf16): 4 sequences x 32 B per lane
-        u32x4 xq[4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s = g * 4 + r;
-            if (s < n) {
+            if (s < n && step < T) {
                 const uint16_t* xp = xproj + ((size_t)row0 + (size_t)s * T + t) * 2048 + xch;
                 xq[r][0] = *(const u32x4*)(xp);
                 xq[r][1] = *(const u32x4*)(xp + 8);
@@ -99,38 +98,47 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
                 xq[r][1] = (u32x4){0u, 0u, 0u, 0u};
             }
         }
-        f32x4 acc[4][4];   // [u16][gate]
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // gate pre-activations of the input projection (bf16, 4 sequences x 32 B per lane) are fetched one step AHEAD: they
+    // come from HBM, and vmcnt completes in order, so a same-step fetch would put a DRAM latency in front of every
+    // streamed weight fragment.
+    u32x4 xq[4][2], xn[4][2];
+    load_x(0, xq);
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        load_x(step + 1, xn);
         const unsigned char* hb = hbuf[cur];
+        unsigned char* hn = hbuf[cur ^ 1];
         // hiding the pointer keeps hipcc from hoisting the STREAMED fragment loads out of the time loop as well
-        // (they would need another 128 VGPRs and spill).
         const bf16x8* wv = wv0;
         asm volatile("" : "+v"(wv));
+        bf16x8 af[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const bf16x8 af = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
+        for (int kk = 0; kk < 8; ++kk) af[kk] = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
+        f32x4 acc[4][4];   // [u16][gate]
+        auto mfma_group = [&](auto a_c) {      // 32 MFMAs: the four gates of 16 hidden units x 16 sequences, K = 256
+            constexpr int a = decltype(a_c)::value;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int fi = (kk * 4 + a) * 4 + q;
+                    constexpr int fi0 = a * 32;
+                    const int fi = fi0 + kk * 4 + q;
                     bf16x8 bfr;
                     if (fi < LSTM_NR) bfr = wreg[fi < LSTM_NR ? fi : 0];
                     else if (fi < LSTM_NR + LSTM_NL) bfr = wl[(size_t)(fi - LSTM_NR) * 64];
                     else bfr = wv[(size_t)fi * 64];
-                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[a][q], 0, 0, 0);
+                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[a][q], 0, 0, 0);
                 }
-        }
-        unsigned char* hn = hbuf[cur ^ 1];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        };
+        auto gate_group = [&](auto a_c) {      // lane-local gate math of the same 16 units (4 sequences per lane)
+            constexpr int a = decltype(a_c)::value;
             const int unit = wave * 64 + a * 16 + u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // lane's 16 xproj values for sequence r: index a*4 + gate
                 const unsigned int w0 = xq[r][a >> 1][(a & 1) * 2], w1 = xq[r][a >> 1][(a & 1) * 2 + 1];
                 const float gi = acc[a][0][r] + __uint_as_float(w0 << 16);
                 const float gf = acc[a][1][r] + __uint_as_float(w0 & 0xffff0000u);
@@ -141,7 +149,17 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
                 const float hv = sigmoid_f(go) * tanh_f(cn);
                 *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
             }
-        }
+        };
+        // software pipeline over the four 16-unit groups: the VALU/transcendental gate math of group a runs in the
+        // issue slots the MFMA stream of group a+1 leaves free (an MFMA holds vector issue for half of its 16 cycles)
+        mfma_group(std::integral_constant<int, 0>{});
+        mfma_group(std::integral_constant<int, 1>{});
+        gate_group(std::integral_constant<int, 0>{});
+        mfma_group(std::integral_constant<int, 2>{});
+        gate_group(std::integral_constant<int, 1>{});
+        mfma_group(std::integral_constant<int, 3>{});
+        gate_group(std::integral_constant<int, 2>{});
+        gate_group(std::integral_constant<int, 3>{});
         __syncthreads();
         // h_t -> out[seq][t][dir*256 + unit], 32 B per thread
         {
@@ -154,6 +172,8 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
                 *(u32x4*)(op + 8) = h1;
             }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xq[r][0] = xn[r][0]; xq[r][1] = xn[r][1]; }
         cur ^= 1;
     }
 }
