@@ -303,15 +303,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
 }
 
 // ------------------------------------------------------------------------------------------------ conv helper
-static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out,
-                     int out_cs, int cout_store, bool out_f32) {
-    if (c->arena.dry) return;
-    ConvArgs a{};
-    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
-    if (a1) { a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C; }
-    a.N = a0.N; a.H = a0.H; a.W = a0.W;
-    a.relu_in0 = relu0; a.relu_in1 = relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
-    a.out = out; a.out_cs = out_cs; a.cout_store = cout_store;
+static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, const ConvArgs& a) {
     if (!c->profiling) {
         HIPCHK(launch_conv(p, a, c->stream));
         return;
@@ -332,6 +324,18 @@ static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0,
     HIPCHK(launch_conv(p, a, c->stream));
     HIPCHK(hipEventRecord(r.e1, c->stream));
     c->prof_recs.push_back(r);
+}
+
+static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out,
+                     int out_cs, int cout_store, bool out_f32) {
+    if (c->arena.dry) return;
+    ConvArgs a{};
+    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
+    if (a1) { a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C; }
+    a.N = a0.N; a.H = a0.H; a.W = a0.W;
+    a.relu_in0 = relu0; a.relu_in1 = relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
+    a.out = out; a.out_cs = out_cs; a.cout_store = cout_store;
+    launch_conv_profiled(c, p, a);
 }
 
 // after the stream has drained: fold the recorded launches into the per-group totals
@@ -357,6 +361,25 @@ static Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, 
     return o;
 }
 
+// conv with the max-pool fused into its epilogue.  mode 1 = MaxPool2d(2,2), 2 = MaxPool2d((2,1),(2,1)).  Returns the pooled
+// activation; when `full` is given the un-pooled conv output (bias, relu_out) is written too (U-net skip tensors).
+static Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, bool relu_out, int store, int mode, bool pool_relu,
+                         Act* full) {
+    const int OH = a0.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a0.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
+    const int PH = OH / 2, PW = mode == 1 ? OW / 2 : OW;
+    if (full) *full = Act{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * store), a0.N, OH, OW, store};
+    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * PH * PW * store), a0.N, PH, PW, store};
+    if (c->arena.dry) return o;
+    ConvArgs a{};
+    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
+    a.N = a0.N; a.H = a0.H; a.W = a0.W;
+    a.relu_in0 = relu0; a.relu_out = relu_out; a.out_f32 = 0;
+    a.out = full ? (void*)full->p : nullptr; a.out_cs = store; a.cout_store = store;
+    a.pool_mode = mode; a.pool_relu = pool_relu; a.store_full = full != nullptr; a.pool_cs = store; a.pool_out = o.p;
+    launch_conv_profiled(c, p, a);
+    return o;
+}
+
 static Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, int ph, int pw, bool relu_in) {
     const int OH = (a.H + 2 * ph - kh) / sh + 1, OW = (a.W + 2 * pw - kw) / sw + 1;
     Act o{c->arena.alloc<uint16_t>((size_t)a.N * OH * OW * a.C), a.N, OH, OW, a.C};
@@ -377,19 +400,16 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     c->prof_group = 0;
     Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
     if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->stream));
-    Act a2 = conv_act(c, c->conv1_2, a1, false, nullptr, false, true, 64);
-    Act p1 = pool_act(c, a2, 2, 2, 2, 2, 0, 0, false);
+    Act p1 = conv_pool_act(c, c->conv1_2, a1, false, true, 64, 1, false, nullptr);          // conv1_2+BN+ReLU+pool fused
     Act a3 = conv_act(c, c->conv2_1, p1, false, nullptr, false, true, 128);
-    Act s1 = conv_act(c, c->conv2_2, a3, false, nullptr, false, false, 128);      // slice1 ends on BatchNorm
-    Act p2 = pool_act(c, s1, 2, 2, 2, 2, 0, 0, true);                              // slice2 opens with ReLU, pool
+    Act s1;                                                                        // slice1 ends on BatchNorm (skip tensor),
+    Act p2 = conv_pool_act(c, c->conv2_2, a3, false, false, 128, 1, true, &s1);   // slice2 opens with ReLU + pool: both fused
     Act a5 = conv_act(c, c->conv3_1, p2, false, nullptr, false, true, 256);
     Act s2 = conv_act(c, c->conv3_2, a5, false, nullptr, false, false, 256);
-    Act a7 = conv_act(c, c->conv3_3, s2, true, nullptr, false, true, 256);         // ReLU applied on load
-    Act p3 = pool_act(c, a7, 2, 2, 2, 2, 0, 0, false);
+    Act p3 = conv_pool_act(c, c->conv3_3, s2, true, true, 256, 1, false, nullptr);  // ReLU applied on load; pool fused
     Act a8 = conv_act(c, c->conv4_1, p3, false, nullptr, false, true, 512);
     Act s3 = conv_act(c, c->conv4_2, a8, false, nullptr, false, false, 512);
-    Act a10 = conv_act(c, c->conv4_3, s3, true, nullptr, false, true, 512);
-    Act p4 = pool_act(c, a10, 2, 2, 2, 2, 0, 0, false);
+    Act p4 = conv_pool_act(c, c->conv4_3, s3, true, true, 512, 1, false, nullptr);
     Act a11 = conv_act(c, c->conv5_1, p4, false, nullptr, false, true, 512);
     Act s4 = conv_act(c, c->conv5_2, a11, false, nullptr, false, false, 512);
     Act p5 = pool_act(c, s4, 3, 3, 1, 1, 1, 1, false);                             // slice5: MaxPool(3,1,1), no ReLU
@@ -660,14 +680,11 @@ static void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, 
     const int T = imgW / 4 - 1;
     Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32), n, 32, imgW / 2, 32};
     if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->stream));
-    Act c1 = conv_act(c, c->r1, c0, false, nullptr, false, true, 64);
-    Act q1 = pool_act(c, c1, 2, 2, 2, 2, 0, 0, false);
+    Act q1 = conv_pool_act(c, c->r1, c0, false, true, 64, 1, false, nullptr);
     Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
-    Act c3 = conv_act(c, c->r3, c2, false, nullptr, false, true, 128);
-    Act q2 = pool_act(c, c3, 2, 1, 2, 1, 0, 0, false);
+    Act q2 = conv_pool_act(c, c->r3, c2, false, true, 128, 2, false, nullptr);
     Act c4 = conv_act(c, c->r4, q2, false, nullptr, false, true, 256);
-    Act c5 = conv_act(c, c->r5, c4, false, nullptr, false, true, 256);
-    Act q3 = pool_act(c, c5, 2, 1, 2, 1, 0, 0, false);
+    Act q3 = conv_pool_act(c, c->r5, c4, false, true, 256, 2, false, nullptr);
     Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [n,3,T,256]
     if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->stream));
 }

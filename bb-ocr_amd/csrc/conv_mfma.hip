@@ -256,13 +256,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
     // ---- epilogue: bias (+ReLU), each lane owns 16 contiguous couts of its pixel per fragment
     const int g = lane >> 4, pl = lane & 15;
     const int cout0 = nt * BN + wn * 64 + g * 16;
-    if (cout0 < a.cout_store) {
-        float bs[16];
+    if (cout0 >= a.cout_store) return;
+    float bs[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + j * 4);
-            bs[j * 4 + 0] = b4[0]; bs[j * 4 + 1] = b4[1]; bs[j * 4 + 2] = b4[2]; bs[j * 4 + 3] = b4[3];
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + j * 4);
+        bs[j * 4 + 0] = b4[0]; bs[j * 4 + 1] = b4[1]; bs[j * 4 + 2] = b4[2]; bs[j * 4 + 3] = b4[3];
+    }
+    auto store16 = [&](void* base, size_t o, const float (&v)[16], bool f32) {
+        if (f32) {
+            float* op = (float*)base + o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(op + j * 4) = (f32x4){v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+        } else {
+            uint16_t* op = (uint16_t*)base + o;
+            const u32x4 lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            const u32x4 hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+            *(u32x4*)(op) = lo;
+            *(u32x4*)(op + 8) = hi;
         }
+    };
+    if (a.pool_mode == 0) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int F = wm * MF + f;
@@ -278,21 +292,56 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
                         if (a.relu_out) x = fmaxf(x, 0.f);
                         v[j * 4 + r] = x;
                     }
-                const size_t o = ((size_t)(n * a.OH + oy) * a.OW + ox) * a.out_cs + cout0;
-                if (a.out_f32) {
-                    float* op = (float*)a.out + o;
+                store16(a.out, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.out_cs + cout0, v, a.out_f32);
+            }
+        }
+        return;
+    }
+    // ---- fused max-pool (MaxPool2d(2,2) or MaxPool2d((2,1),(2,1))): the two rows of a pooling window are two fragments of
+    // this wave (the launcher only picks tiles with MF % (2*fpr) == 0), the two columns are lanes l and l^1.
+    auto pooled = [&](auto fpr_c) {
+        constexpr int FPR = decltype(fpr_c)::value;
+        if constexpr (MF % (2 * FPR) == 0) {
+            const int POH = a.OH >> 1, POW = a.pool_mode == 1 ? (a.OW >> 1) : a.OW;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) *(f32x4*)(op + j * 4) = (f32x4){v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+            for (int f = 0; f < MF; ++f) {
+                if ((f / FPR) & 1) continue;                 // odd tile rows are consumed by their even partner
+                const int F = wm * MF + f;
+                const int fr = F / FPR, fc = F - fr * FPR;
+                const int oy = oy0 + fr, ox = ox0 + fc * 16 + pl;
+                float v0[16], v1[16], m[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x0 = acc[f][j][r] + bs[j * 4 + r], x1 = acc[f + FPR][j][r] + bs[j * 4 + r];
+                        if (a.relu_out) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        v0[j * 4 + r] = x0;
+                        v1[j * 4 + r] = x1;
+                        float p = fmaxf(x0, x1);
+                        if (a.pool_relu) p = fmaxf(p, 0.f);
+                        m[j * 4 + r] = p;
+                    }
+                if (a.store_full && ox < a.OW) {
+                    if (oy < a.OH) store16(a.out, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.out_cs + cout0, v0, a.out_f32);
+                    if (oy + 1 < a.OH) store16(a.out, ((size_t)(n * a.OH + oy + 1) * a.OW + ox) * a.out_cs + cout0, v1, a.out_f32);
+                }
+                if (a.pool_mode == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], 1));
+                    const int py = oy >> 1, px = ox >> 1;
+                    if (!(pl & 1) && py < POH && px < POW)
+                        store16(a.pool_out, ((size_t)(n * POH + py) * POW + px) * a.pool_cs + cout0, m, false);
                 } else {
-                    uint16_t* op = (uint16_t*)a.out + o;
-                    u32x4 lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                    u32x4 hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-                    *(u32x4*)(op) = lo;
-                    *(u32x4*)(op + 8) = hi;
+                    const int py = oy >> 1;
+                    if (py < POH && ox < POW) store16(a.pool_out, ((size_t)(n * POH + py) * POW + ox) * a.pool_cs + cout0, m, false);
                 }
             }
         }
-    }
+    };
+    if (fpr == 1) pooled(std::integral_constant<int, 1>{});
+    else if (fpr == 2) pooled(std::integral_constant<int, 2>{});
+    else pooled(std::integral_constant<int, 4>{});
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -382,6 +431,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             const int pit = cdiv(np / 16, NWV), pit_r = pit <= 4 ? 4 : (pit <= 8 ? 8 : 16), nparts = pit_r / 4;
             if (pit > max_piter || (size_t)ring * BN * 64 + (size_t)2 * np * 64 > 160 * 1024) continue;
             if (a.ntaps >= 3 ? (a.ntaps - 1) / nparts < 1 : nparts > 1) continue;
+            if (a.pool_mode && (small ? (BN == 128 ? 8 : 4) : (BN == 64 ? 4 : 8)) % (2 * (tw / 16)) != 0) continue;
             const long long tiles = (long long)cdiv(a.OH, th) * cdiv(a.OW, tw);
             const long long cost = tiles * ((long long)BM * a.ntaps + 2LL * np);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = np; }

@@ -19,6 +19,9 @@ struct ConvArgs {
     int relu_in0, relu_in1, relu_out, out_f32;
     int out_cs, cout_store;  // output pixel stride (elements), couts actually stored (multiple of 16)
     int nchunks, ntaps;
+    // fused max-pool in the epilogue: 0 none, 1 = MaxPool2d(2,2), 2 = MaxPool2d((2,1),(2,1)); bf16 output [N,OH/2,OW(/2),pool_cs]
+    int pool_mode, pool_relu, store_full, pool_cs;
+    void* pool_out;
 };
 
 struct ConvPlan {      // host-side description of one packed conv layer
