@@ -69,7 +69,7 @@ PROTOTYPES = {
     "bbocr_host_component_polys": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]),
     "bbocr_host_group_boxes": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(bbocr_params), C.POINTER(C.POINTER(bbocr_boxlist))]),
     "bbocr_op_conv2d": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "bbocr_crnn_logits": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "bbocr_op_ctc": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "bbocr_op_resize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),

@@ -1231,20 +1231,28 @@ int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr
 
 // ---------------------------------------------------------------------------------------- single-operator entry points
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, int KH,
-                    int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out) {
+                    int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
+                    uint16_t* dev_pool_out) {
     return guarded(ctx, [&] {
-        if (!dev_in || !w || !dev_out || Cin <= 0 || (Cin & 31) || Cout <= 0 || KH <= 0 || KW <= 0) fail(BBOCR_ERR_ARG, "bad conv arguments");
+        if (!dev_in || !w || Cin <= 0 || (Cin & 31) || Cout <= 0 || KH <= 0 || KW <= 0) fail(BBOCR_ERR_ARG, "bad conv arguments");
+        if (pool_mode < 0 || pool_mode > 2 || (pool_mode ? (!dev_pool_out || out_f32) : !dev_out)) fail(BBOCR_ERR_ARG, "bad conv output arguments");
         ConvPlan p = make_plan(Cin, Cout, KH, KW, pad, dil);
         std::vector<float> wv(w, w + (size_t)Cout * Cin * KH * KW), bv(Cout, 0.f);
         if (bias) std::copy(bias, bias + Cout, bv.begin());
         const size_t owned0 = ctx->owned.size();
         upload_plan(ctx, p, wv, bv);
         const int store = cdiv(Cout, 16) * 16;
-        Act a{const_cast<uint16_t*>(dev_in), N, H, W, Cin};
-        ctx->arena.dry = false;
-        run_conv(ctx, p, a, relu_in != 0, nullptr, false, relu_out != 0, dev_out, store, store, out_f32 != 0);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ConvArgs a{};
+        a.in0 = dev_in; a.C0 = Cin; a.in0_cs = Cin;
+        a.N = N; a.H = H; a.W = W;
+        a.relu_in0 = relu_in != 0; a.relu_out = relu_out != 0; a.out_f32 = out_f32 != 0;
+        a.out = dev_out; a.out_cs = store; a.cout_store = store;
+        a.pool_mode = pool_mode; a.pool_relu = pool_relu != 0; a.store_full = (pool_mode && dev_out) ? 1 : 0; a.pool_cs = store; a.pool_out = dev_pool_out;
+        const hipError_t e = launch_conv(p, a, ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
         while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); }
+        HIPCHK(e);
+        HIPCHK(e2);
     });
 }
 

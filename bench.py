@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--lines", type=int, default=20)
     ap.add_argument("--cpu-pages", type=int, default=2, help="pages for the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
 
     import numpy as np
@@ -51,12 +52,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one card
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import bb_ocr_amd
     from bb_ocr_amd import dist as bdist
@@ -67,8 +73,9 @@ def main():
     if rank == 0:
         cs, rs = weights.designed_craft_state(0), weights.synthetic_crnn_state(0)
     if world > 1:
-        cs = bdist.broadcast_state(cs, 0, device=f"cuda:{local_rank}")
-        rs = bdist.broadcast_state(rs, 0, device=f"cuda:{local_rank}")
+        bdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+        cs = bdist.broadcast_state(cs, 0, device=bdev)
+        rs = bdist.broadcast_state(rs, 0, device=bdev)
     reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=(cs, rs), device_index=local_rank, det_sub_batch=args.det_sub_batch)
 
     # ---- this rank's shard of the global batch (contiguous block), rendered on the host, then resident in HBM
@@ -106,7 +113,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     conv_ms, conv_flops, conv_launches = reader.conv_profile(0)

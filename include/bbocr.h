@@ -146,9 +146,12 @@ int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr
 
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
- * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout). */
+ * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout).
+ * pool_mode 1/2 fuses MaxPool2d(2,2) / MaxPool2d((2,1),(2,1)) (optionally after ReLU: pool_relu) into the epilogue and
+ * writes bf16 [N,OH/2,OW/2 or OW,Cout_store] to dev_pool_out; dev_out may then be NULL (pooled output only). */
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
-                    int KH, int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out);
+                    int KH, int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
+                    uint16_t* dev_pool_out);
 /* recogniser network only: crops bf16 [n,64,imgW] (device, already normalised) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);
 /* greedy CTC on logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n] */

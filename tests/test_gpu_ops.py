@@ -32,7 +32,7 @@ def _conv_case(reader, N, H, W, Cin, Cout, K, pad, dil, relu_in, relu_out, out_f
     bn = np.ascontiguousarray(b.numpy(), dtype=np.float32)
     rc = reader._lib.bbocr_op_conv2d(reader._h, C.c_void_p(xd.data_ptr()), N, H, W, Cin, wn.ctypes.data_as(C.POINTER(C.c_float)),
                                      bn.ctypes.data_as(C.POINTER(C.c_float)), Cout, K, K, pad, dil, int(relu_in), int(relu_out), int(out_f32),
-                                     C.c_void_p(out.data_ptr()))
+                                     C.c_void_p(out.data_ptr()), 0, 0, None)
     reader._check(rc)
     got = out.float().cpu()[..., :Cout]
     assert torch.isfinite(got).all()
@@ -67,6 +67,42 @@ def _conv_case(reader, N, H, W, Cin, Cout, K, pad, dil, relu_in, relu_out, out_f
 ])
 def test_conv_mfma_vs_fp64(reader, cfg):
     _conv_case(reader, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, mode, relu_out, pool_relu, store_full
+    (2, 32, 48, 64, 64, 1, 1, 0, 0),       # conv1_2-like: pooled output only
+    (1, 30, 44, 64, 128, 1, 0, 1, 1),      # conv2_2-like: skip tensor (no ReLU) + ReLU'd pooled tensor
+    (1, 22, 38, 128, 256, 1, 1, 0, 0),     # ragged tiles, odd tile counts
+    (2, 16, 70, 128, 128, 2, 1, 0, 0),     # CRNN (2,1) pool
+    (1, 8, 90, 256, 256, 2, 1, 0, 0),      # H = 8 tile rows
+    (1, 64, 40, 32, 64, 1, 1, 0, 0),       # BN=64 config
+])
+def test_conv_fused_maxpool(reader, cfg):
+    N, H, W, Cin, Cout, mode, relu_out, pool_relu, store_full = cfg
+    g = torch.Generator().manual_seed(7)
+    x = _bf16(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    y = F.conv2d(x.double(), _bf16(w).double(), b.double(), padding=1)
+    full_ref = (F.relu(y) if relu_out else y)
+    pin = F.relu(full_ref) if pool_relu else full_ref
+    pooled_ref = F.max_pool2d(pin, (2, 2) if mode == 1 else (2, 1)).permute(0, 2, 3, 1).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    full = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    pooled = torch.full(tuple(pooled_ref.shape), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wn = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bn = np.ascontiguousarray(b.numpy(), dtype=np.float32)
+    rc = reader._lib.bbocr_op_conv2d(reader._h, C.c_void_p(xd.data_ptr()), N, H, W, Cin, wn.ctypes.data_as(C.POINTER(C.c_float)),
+                                     bn.ctypes.data_as(C.POINTER(C.c_float)), Cout, 3, 3, 1, 1, 0, int(relu_out), 0,
+                                     C.c_void_p(full.data_ptr()) if store_full else None, mode, int(pool_relu), C.c_void_p(pooled.data_ptr()))
+    reader._check(rc)
+    tol = 6e-3 * max(y.abs().max().item(), 1.0)
+    got = pooled.float().cpu()
+    assert torch.isfinite(got).all() and (got - pooled_ref).abs().max().item() <= tol
+    if store_full:
+        gf = full.float().cpu()
+        assert torch.isfinite(gf).all() and (gf - full_ref.permute(0, 2, 3, 1).float()).abs().max().item() <= tol
 
 
 def test_resize_u8_bit_exact(reader):
