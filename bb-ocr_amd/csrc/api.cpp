@@ -105,6 +105,7 @@ struct bbocr_ctx {
     uint16_t* whh[2] = {nullptr, nullptr};
     std::vector<void*> owned;    // every hipMalloc'd weight block
 
+    void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
     Arena arena;
     DevBuf heat, gray, resized;
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
@@ -303,7 +304,8 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
 }
 
 // ------------------------------------------------------------------------------------------------ conv helper
-static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, const ConvArgs& a) {
+static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
+    a.zero = c->zero_page;
     if (!c->profiling) {
         HIPCHK(launch_conv(p, a, c->stream));
         return;
@@ -1021,7 +1023,8 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
             delete c;
             return BBOCR_ERR_HIP;
         }
-        if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
             delete c;
             return BBOCR_ERR_HIP;
         }
@@ -1045,6 +1048,7 @@ void bbocr_destroy(bbocr_ctx* c) {
                       &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
                       &c->seq_tables};
     for (DevBuf* b : bufs) b->release();
+    if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1248,6 +1252,7 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
         a.relu_in0 = relu_in != 0; a.relu_out = relu_out != 0; a.out_f32 = out_f32 != 0;
         a.out = dev_out; a.out_cs = store; a.cout_store = store;
         a.pool_mode = pool_mode; a.pool_relu = pool_relu != 0; a.store_full = (pool_mode && dev_out) ? 1 : 0; a.pool_cs = store; a.pool_out = dev_pool_out;
+        a.zero = ctx->zero_page;
         const hipError_t e = launch_conv(p, a, ctx->stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
         while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); }

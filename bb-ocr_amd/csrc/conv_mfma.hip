@@ -17,243 +17,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <utility>
 
-// 512-thread configs run one workgroup per CU (2 waves/SIMD inside it); 256-thread configs are built for TWO co-resident
-// workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
-template <int WM, int WN, int MF, int PITER, bool PIPE>
-__global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvArgs a) {
-    constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
-    constexpr int WBUF = BN * 64;          // bytes of one weight k-step slice (BN couts x 32 k x 2 B)
-    constexpr int WPIECES = WBUF / 16;     // 16-B pieces per slice
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WRING = PIPE ? 3 : 2;
-    unsigned char* const wbuf = smem;                  // [WRING][WBUF]
-    unsigned char* const pbuf = smem + WRING * WBUF;   // [2][NP*64]
-    const int patch_bytes = a.NP * 64;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = bid % a.ntiles_n;
-    bid /= a.ntiles_n;
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
-    const int nk = a.nchunks * a.ntaps;
-
-    // ---- patch loader: one wave-instruction = 16 patch pixels x 4 channel groups (64 B contiguous per pixel).
-    // lane -> (pixel, group) chosen so each 8-lane ds_write group hits 8 consecutive 16-B slots of one group.
-    const int n_wi = a.NP >> 4;
-    const int l_pix = (lane & 7) + ((lane >> 5) << 3);
-    const int l_kg = (lane >> 3) & 3;
-    int src_pix[PITER];   // input pixel index (n,iy,ix flattened) or -1 when the slot is zero padding
-#pragma unroll
-    for (int it = 0; it < PITER; ++it) {
-        const int wi = wave + it * NW;
-        int sp = -1;
-        if (wi < n_wi) {
-            const int pix = wi * 16 + l_pix;
-            const int py = pix / a.PW, px = pix - py * a.PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            if (py < a.PH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) sp = (n * a.H + iy) * a.W + ix;
-        }
-        src_pix[it] = sp;
-    }
-    // The patch of one chunk is staged in NPART parts so that at most PH x 4 VGPRs are in flight at once.
-    constexpr int NPART = (PITER + 3) / 4, PH = PITER / NPART;   // PITER 4/8/16 -> 1/2/4 parts of 4 wave-instructions
-    u32x4 pre[PH];
-    auto load_part = [&](int chunk, auto part_c) {
-        constexpr int part = decltype(part_c)::value;
-        const int c = chunk * 32;
-        const bool s0 = c < a.C0;
-        const uint16_t* src = s0 ? a.in0 : a.in1;
-        const int cs = s0 ? a.in0_cs : a.in1_cs;
-        const int cb = (s0 ? c : c - a.C0) + l_kg * 8;
-        const bool relu = s0 ? a.relu_in0 : a.relu_in1;
-#pragma unroll
-        for (int i = 0; i < PH; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (src_pix[part * PH + i] >= 0) {
-                v = *(const u32x4*)(src + (size_t)src_pix[part * PH + i] * cs + cb);
-                if (relu) {
-                    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
-                }
-            }
-            pre[i] = v;
-        }
-    };
-    auto store_part = [&](int buf, auto part_c) {
-        constexpr int part = decltype(part_c)::value;
-        unsigned char* pb = pbuf + buf * patch_bytes;
-#pragma unroll
-        for (int i = 0; i < PH; ++i) {
-            const int wi = wave + (part * PH + i) * NW;
-            if (wi < n_wi) *(u32x4*)(pb + (size_t)(l_kg * a.NP + wi * 16 + l_pix) * 16) = pre[i];
-        }
-    };
-    using P0 = std::integral_constant<int, 0>;
-    // staging schedule inside a chunk with >= 3 taps: part i of the NEXT chunk is loaded at tap i*S and stored at tap
-    // i*S + S - 1, S = (ntaps-1)/NPART, so the last store lands at tap <= ntaps-2 (the pipelined schedule reads the next
-    // chunk's first fragments during the last tap) and at most one part (PH x 4 VGPRs) is in flight.
-    const int S = (a.ntaps - 1) / NPART;
-    auto stage_patch_load = [&](int chunk, int tap) {
-        if (tap == 0) load_part(chunk, P0{});
-        if constexpr (NPART > 1) { if (tap == S) load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
-        if constexpr (NPART > 2) { if (tap == 2 * S) load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
-        if constexpr (NPART > 3) { if (tap == 3 * S) load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
-    };
-    auto stage_patch_store = [&](int chunk, int tap) {
-        if (tap == S - 1) store_part(chunk & 1, P0{});
-        if constexpr (NPART > 1) { if (tap == 2 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
-        if constexpr (NPART > 2) { if (tap == 3 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
-        if constexpr (NPART > 3) { if (tap == 4 * S - 1) store_part(chunk & 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
-    };
-    auto stage_patch_now = [&](int chunk) {        // prologue: whole patch, synchronously
-        load_part(chunk, P0{});
-        store_part(chunk & 1, P0{});
-        if constexpr (NPART > 1) { load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
-        if constexpr (NPART > 2) { load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
-        if constexpr (NPART > 3) { load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); store_part(chunk & 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
-    };
-    // ---- weight slice: LDS-DMA, LDS image == global image (fragment order), lane-linear
-    const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
-    auto issue_w = [&](int ks, int buf) {
-#pragma unroll
-        for (int p0 = 0; p0 < WPIECES; p0 += NT) {
-            if (p0 + wave * 64 < WPIECES) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
-                    (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF + (p0 + wave * 64) * 16), 16, 0, 0);
-            }
-        }
-    };
-
-    // ---- per-wave fragment geometry
-    const int fpr = a.TW >> 4;   // 16-pixel fragments per tile row
-    int frag_off[MF];
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-        const int F = wm * MF + f;
-        const int fr = F / fpr, fc = F - fr * fpr;
-        frag_off[f] = (fr * a.PW + fc * 16) * 16;
-    }
-    const int lane_patch_off = ((lane >> 4) * a.NP + (lane & 15)) * 16;
-    const int lane_w_off = wn * 4 * 1024 + lane * 16;
-
-    f32x4 acc[MF][4];
-#pragma unroll
-    for (int f = 0; f < MF; ++f)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if constexpr (!PIPE) {
-        // reference schedule: 2-deep weight ring, fragments read at the top of every k-step
-        issue_w(0, 0);
-        stage_patch_now(0);
-        __syncthreads();
-        int ks = 0;
-        for (int c = 0; c < a.nchunks; ++c) {
-            const bool more = (c + 1 < a.nchunks);
-            if (more && a.ntaps < 3) load_part(c + 1, P0{});
-            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
-            int ky = 0, kx = 0;
-            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
-                if (more && a.ntaps >= 3) stage_patch_load(c + 1, tap);
-                if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
-                const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
-                bf16x8 af[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
-                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
-                // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
-                // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
-                bf16x8 bq[MF];
-#pragma unroll
-                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
-#pragma unroll
-                for (int f = 0; f < MF; ++f) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-                }
-                // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
-                if (more) {
-                    if (a.ntaps >= 3) stage_patch_store(c + 1, tap);
-                    else if (tap == a.ntaps - 1) store_part((c + 1) & 1, P0{});
-                }
-                __syncthreads();
-                if (++kx == a.KW) { kx = 0; ++ky; }
-            }
-        }
-    } else {
-        // software-pipelined schedule (taps >= 3): 3-deep weight ring; each k-step is two halves of 2*MF MFMAs.  While
-        // the first half issues, the second half's activation fragments are in flight; while the second half issues, the
-        // NEXT k-step's weight fragments and first-half activation fragments are in flight.  A wave therefore leaves the
-        // barrier with operands in registers and never waits on LDS latency in front of an MFMA group.  The next chunk's
-        // patch must be visible one k-step earlier than in the reference schedule (stored by tap ntaps-2).
-        constexpr int HF = MF / 2;
-        issue_w(0, 0);
-        if (nk > 1) issue_w(1, 1);
-        stage_patch_now(0);
-        __syncthreads();
-        bf16x8 af[4], an[4], bq[MF];
-        {
-            const unsigned char* wb = wbuf + lane_w_off;
-            const unsigned char* pb = pbuf + lane_patch_off;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
-#pragma unroll
-            for (int f = 0; f < HF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
-        }
-        int c = 0, tap = 0, ky = 0, kx = 0, wslot = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-            const bool more = (c + 1 < a.nchunks);
-            if (more) stage_patch_load(c + 1, tap);
-            if (ks + 2 < nk) issue_w(ks + 2, wslot == 0 ? 2 : wslot - 1);   // slot (ks+2)%3 == (ks-1)%3
-            int c1 = c, tap1 = tap + 1, ky1 = ky, kx1 = kx + 1;
-            if (kx1 == a.KW) { kx1 = 0; ++ky1; }
-            if (tap1 == a.ntaps) { tap1 = 0; ky1 = 0; kx1 = 0; ++c1; }
-            const bool has_next = (ks + 1 < nk);
-            const int wslot1 = wslot == 2 ? 0 : wslot + 1;
-            const unsigned char* pb0 = pbuf + (c & 1) * patch_bytes + lane_patch_off + ((ky * a.PW + kx) * a.dil) * 16;
-            // the last k-step re-reads its own operands instead of branching around the prefetch
-            const unsigned char* wb1 = wbuf + (has_next ? wslot1 : wslot) * WBUF + lane_w_off;
-            const unsigned char* pb1 = has_next ? pbuf + (c1 & 1) * patch_bytes + lane_patch_off + ((ky1 * a.PW + kx1) * a.dil) * 16 : pb0;
-#pragma unroll
-            for (int f = HF; f < MF; ++f) bq[f] = *(const bf16x8*)(pb0 + frag_off[f]);
-#pragma unroll
-            for (int f = 0; f < HF; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) an[j] = *(const bf16x8*)(wb1 + j * 1024);
-#pragma unroll
-            for (int f = 0; f < HF; ++f) bq[f] = *(const bf16x8*)(pb1 + frag_off[f]);
-#pragma unroll
-            for (int f = HF; f < MF; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, HF, 0);          // second-half activation reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * HF, 0);      // first-half MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + HF, 0);      // next k-step: weights + first-half activations
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * HF, 0);      // second-half MFMAs
-#pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = an[j];
-            if (more) stage_patch_store(c + 1, tap);
-            __syncthreads();
-            c = c1; tap = tap1; ky = ky1; kx = kx1; wslot = wslot1;
-        }
-    }
-
-    // ---- epilogue: bias (+ReLU), each lane owns 16 contiguous couts of its pixel per fragment
+// ---- shared epilogue: bias (+ReLU) (+fused max-pool); each lane owns 16 contiguous couts of its pixel per fragment
+template <int MF>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn, int fpr,
+                                              int lane, int BN) {
     const int g = lane >> 4, pl = lane & 15;
     const int cout0 = nt * BN + wn * 64 + g * 16;
     if (cout0 >= a.cout_store) return;
@@ -344,6 +113,454 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
     else pooled(std::integral_constant<int, 4>{});
 }
 
+// 512-thread configs run one workgroup per CU (2 waves/SIMD inside it); 256-thread configs are built for TWO co-resident
+// workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
+template <int WM, int WN, int MF, int PITER, int RING>
+__global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
+    constexpr int WBUF = BN * 64;          // bytes of one weight k-step slice (BN couts x 32 k x 2 B)
+    constexpr int WPIECES = WBUF / 16;     // 16-B pieces per slice
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WRING = RING;
+    unsigned char* const wbuf = smem;                  // [WRING][WBUF]
+    unsigned char* const pbuf = smem + WRING * WBUF;   // [2][NP*64]
+    const int patch_bytes = a.NP * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % a.ntiles_n;
+    bid /= a.ntiles_n;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
+    const int nk = a.nchunks * a.ntaps;
+
+    // ---- patch loader: one wave-instruction = 16 patch pixels x 4 channel groups (64 B contiguous per pixel).
+    // lane -> (pixel, group) chosen so each 8-lane ds_write group hits 8 consecutive 16-B slots of one group.
+    const int n_wi = a.NP >> 4;
+    const int l_pix = (lane & 7) + ((lane >> 5) << 3);
+    const int l_kg = (lane >> 3) & 3;
+    int src_pix[PITER];   // input pixel index (n,iy,ix flattened) or -1 when the slot is zero padding
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+        const int wi = wave + it * NW;
+        int sp = -1;
+        if (wi < n_wi) {
+            const int pix = wi * 16 + l_pix;
+            const int py = pix / a.PW, px = pix - py * a.PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if (py < a.PH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) sp = (n * a.H + iy) * a.W + ix;
+        }
+        src_pix[it] = sp;
+    }
+    // The patch of one chunk is staged in NPART parts so that at most PH x 4 VGPRs are in flight at once.
+    constexpr int NPART = (PITER + 3) / 4, PH = PITER / NPART;   // PITER 4/8/16 -> 1/2/4 parts of 4 wave-instructions
+    u32x4 pre[PH];
+    // Loads only ISSUE here; masking of out-of-image slots and the ReLU-on-load are applied in store_part, right before the
+    // ds_write, so nothing touches the loaded registers (and forces a vmcnt wait) while the loads are in flight.
+    auto load_part = [&](int chunk, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
+        const int c = chunk * 32;
+        const bool s0 = c < a.C0;
+        const uint16_t* src = s0 ? a.in0 : a.in1;
+        const int cs = s0 ? a.in0_cs : a.in1_cs;
+        const int cb = (s0 ? c : c - a.C0) + l_kg * 8;
+        int issued = 0;
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const int sp = src_pix[part * PH + i];
+            if constexpr (RING == 2) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (sp >= 0 && !(a.dbg & 2)) v = *(const u32x4*)(src + (size_t)sp * cs + cb);   // dbg bit 2: timing-only ablation
+                pre[i] = v;
+            } else {
+                // counted-wait schedule: the number of loads a wave ISSUES must be known exactly (vmcnt bookkeeping): the
+                // wave-uniform guard below is the only condition; out-of-image lanes read pixel 0 and are zeroed at store time
+                if (wave + (part * PH + i) * NW < n_wi) {
+                    pre[i] = *(const u32x4*)(src + (size_t)(sp >= 0 ? sp : 0) * cs + cb);
+                    ++issued;
+                }
+            }
+        }
+        return issued;
+    };
+    auto store_part = [&](int chunk, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
+        unsigned char* pb = pbuf + (chunk & 1) * patch_bytes;
+        const bool relu = (chunk * 32 < a.C0) ? a.relu_in0 : a.relu_in1;
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const int wi = wave + (part * PH + i) * NW;
+            if (wi < n_wi) {
+                u32x4 v = pre[i];
+                if (RING != 2 && src_pix[part * PH + i] < 0) v = (u32x4){0u, 0u, 0u, 0u};
+                if (relu) {
+                    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+                }
+                *(u32x4*)(pb + (size_t)(l_kg * a.NP + wi * 16 + l_pix) * 16) = v;
+            }
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    // staging schedule inside a chunk with >= 3 taps: part i of the NEXT chunk is loaded at tap i*S and stored at tap
+    // i*S + S - 1, S = (ntaps-1)/NPART, so the last store lands at tap <= ntaps-2 (the pipelined schedule reads the next
+    // chunk's first fragments during the last tap) and at most one part (PH x 4 VGPRs) is in flight.
+    const int S = (a.ntaps - 1) / NPART;
+    auto stage_patch_load = [&](int chunk, int tap) {
+        if (tap == 0) load_part(chunk, P0{});
+        if constexpr (NPART > 1) { if (tap == S) load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { if (tap == 2 * S) load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { if (tap == 3 * S) load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
+    };
+    auto stage_patch_store = [&](int chunk, int tap) {
+        if (tap == S - 1) store_part(chunk, P0{});
+        if constexpr (NPART > 1) { if (tap == 2 * S - 1) store_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { if (tap == 3 * S - 1) store_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { if (tap == 4 * S - 1) store_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
+    };
+    auto stage_patch_now = [&](int chunk) {        // prologue: whole patch, synchronously
+        load_part(chunk, P0{});
+        store_part(chunk, P0{});
+        if constexpr (NPART > 1) { load_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); store_part(chunk, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+        if constexpr (NPART > 2) { load_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); store_part(chunk, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+        if constexpr (NPART > 3) { load_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); store_part(chunk, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
+    };
+    // ---- weight slice: LDS-DMA, LDS image == global image (fragment order), lane-linear
+    const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
+    auto issue_w = [&](int ks, int buf) {
+        if (a.dbg & 1) return;   // timing-only ablation (BBOCR_CONV_DBG): no weight DMA, results are garbage
+#pragma unroll
+        for (int p0 = 0; p0 < WPIECES; p0 += NT) {
+            if (p0 + wave * 64 < WPIECES) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
+                    (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF + (p0 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- per-wave fragment geometry
+    const int fpr = a.TW >> 4;   // 16-pixel fragments per tile row
+    int frag_off[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int F = wm * MF + f;
+        const int fr = F / fpr, fc = F - fr * fpr;
+        frag_off[f] = (fr * a.PW + fc * 16) * 16;
+    }
+    const int lane_patch_off = ((lane >> 4) * a.NP + (lane & 15)) * 16;
+    const int lane_w_off = wn * 4 * 1024 + lane * 16;
+
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (RING == 2) {
+        // reference schedule: 2-deep weight ring, fragments read at the top of every k-step
+        issue_w(0, 0);
+        stage_patch_now(0);
+        __syncthreads();
+        int ks = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            const bool more = (c + 1 < a.nchunks);
+            if (more && a.ntaps < 3) load_part(c + 1, P0{});
+            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
+                if (more && a.ntaps >= 3) stage_patch_load(c + 1, tap);
+                if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
+                const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
+                bf16x8 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
+                // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
+                // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
+                bf16x8 bq[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+                }
+                // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
+                if (more) {
+                    if (a.ntaps >= 3) stage_patch_store(c + 1, tap);
+                    else if (tap == a.ntaps - 1) store_part(c + 1, P0{});
+                }
+                if (a.dbg & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // dbg bit 8: asm form of the barrier
+                else __syncthreads();
+                if (++kx == a.KW) { kx = 0; ++ky; }
+            }
+        }
+    } else {
+        // deep-ring counted-wait schedule (256-thread configs: every wave issues WPT weight DMAs per slice).
+        // Weight slice ks+RING-1 is issued at k-step ks, FIRST among the k-step's VMEM operations; the next chunk's
+        // activation loads follow it.  vmcnt retires in order, so the barrier at the end of k-step ks only has to make
+        // slice ks+1 (issued RING-2 k-steps ago) visible: it waits with a COUNTED vmcnt that leaves every younger
+        // operation in flight -- RING-2 k-steps of weight DMA and activation loads ride across the barriers, which
+        // gives an HBM-latency activation load up to RING k-steps before anything has to wait for it.
+        constexpr int WPT = WPIECES / NT;
+        static_assert(WPIECES % NT == 0 && RING >= 3 && RING <= 4, "counted schedule needs uniform DMA issue");
+        constexpr int NMAX = PH + (RING - 2) * (WPT + PH);
+        auto wait_vm_barrier = [&](int nvm) {      // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
+#define BBOCR_WVM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            switch (nvm) {
+                BBOCR_WVM(0) BBOCR_WVM(1) BBOCR_WVM(2) BBOCR_WVM(3) BBOCR_WVM(4) BBOCR_WVM(5) BBOCR_WVM(6) BBOCR_WVM(7) BBOCR_WVM(8)
+                BBOCR_WVM(9) BBOCR_WVM(10) BBOCR_WVM(11) BBOCR_WVM(12) BBOCR_WVM(13) BBOCR_WVM(14) BBOCR_WVM(15) BBOCR_WVM(16)
+                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            }
+#undef BBOCR_WVM
+        };
+        static_assert(NMAX <= 16, "extend the vmcnt dispatch table");
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i)
+            if (i < nk) issue_w(i, i);
+        stage_patch_now(0);
+        __syncthreads();
+        // VMEM operations issued in k-steps ks-2, ks-1 (hw/hp: weight DMAs / activation loads still unconsumed)
+        int hw1 = 0, hp1 = 0, hp2 = 0;
+        int ks = 0, wslot = 0;
+        for (int c = 0; c < a.nchunks; ++c) {
+            const bool more = (c + 1 < a.nchunks);
+            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
+                int w_now = 0, p_now = 0;
+                if (ks + RING - 1 < nk) {
+                    int slot = wslot + RING - 1;
+                    if (slot >= RING) slot -= RING;
+                    issue_w(ks + RING - 1, slot);
+                    w_now = WPT;
+                }
+                if (more) {
+                    if (a.ntaps >= 3) {
+                        if (tap == 0) p_now = load_part(c + 1, P0{});
+                        if constexpr (NPART > 1) { if (tap == S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
+                        if constexpr (NPART > 2) { if (tap == 2 * S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
+                        if constexpr (NPART > 3) { if (tap == 3 * S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
+                    } else if (tap == 0) {
+                        p_now = load_part(c + 1, P0{});
+                    }
+                }
+                const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
+                bf16x8 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
+                bf16x8 bq[MF];
+#pragma unroll
+                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
+                // stores: hipcc waits for the stored part's loads by itself; that part then no longer counts as in flight
+                if (more) {
+                    bool stored = false;
+                    int age = 0;   // k-steps since the stored part was loaded
+                    if (a.ntaps >= 3) {
+                        if (tap == S - 1) { store_part(c + 1, P0{}); stored = true; age = S - 1; }
+                        if constexpr (NPART > 1) { if (tap == 2 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); stored = true; age = S - 1; } }
+                        if constexpr (NPART > 2) { if (tap == 3 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); stored = true; age = S - 1; } }
+                        if constexpr (NPART > 3) { if (tap == 4 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); stored = true; age = S - 1; } }
+                    } else if (tap == a.ntaps - 1) {
+                        store_part(c + 1, P0{});
+                        stored = true;
+                        age = a.ntaps - 1;
+                    }
+                    if (stored) {
+                        if (age == 0) p_now = 0;
+                        else if (age == 1) hp1 = 0;
+                        else if (age == 2) hp2 = 0;
+                    }
+                }
+                // operations younger than slice ks+1 (issued first in k-step ks-(RING-2)): what that k-step issued after
+                // it, plus everything of the k-steps since
+                int nvm;
+                if constexpr (RING == 3) nvm = hp1 + w_now + p_now;
+                else nvm = hp2 + hw1 + hp1 + w_now + p_now;
+                wait_vm_barrier((a.dbg & 4) ? 0 : nvm);   // dbg bit 4: drain everything (A/B of the counted wait itself)
+                hp2 = hp1; hp1 = p_now; hw1 = w_now;
+                if (++kx == a.KW) { kx = 0; ++ky; }
+                wslot = wslot + 1 == RING ? 0 : wslot + 1;
+            }
+        }
+    }
+
+    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
+}
+
+// ================================================================================================ 3x3, LDS-DMA staged
+// Variant for 3x3 / pad 1 / dilation 1 layers (every big layer of CRAFT and the CRNN): BOTH operands reach LDS by LDS-DMA
+// (global_load_lds_dwordx4), so the main loop holds no global->register loads at all, hipcc inserts no vmcnt waits of its
+// own, and the schedule is fully static:
+//   * activation patch: wave w copies channel group w of the NEXT chunk, one 64-pixel DMA per tap for the first NPB taps
+//     (per-lane source address = the pixel's 16 bytes, or a zero page for padding); LDS image [group][NP = 64*NPB pixels];
+//   * weights: slice ks+RING-1 is issued at k-step ks, first among the k-step's VMEM operations;
+//   * every k-step ends with `s_waitcnt vmcnt(N)` + s_barrier where N (a compile-time constant per tap) is the number of
+//     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
+// vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
+// issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
+template <int WM, int WN, int MF, int NPB, int RING>
+__global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
+    static_assert(NW == 4, "one wave per 8-channel group of the patch");
+    constexpr int WBUF = BN * 64, WPIECES = WBUF / 16, WPT = WPIECES / NT;
+    static_assert(WPIECES % NT == 0 && (RING == 3 || RING == 4), "uniform DMA issue");
+    constexpr int NP = NPB * 64, PSLOTS = 10 - RING;      // taps 0 .. 9-RING may issue patch DMAs
+    static_assert(NPB <= 2 * PSLOTS, "patch does not fit the DMA schedule");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wbuf = smem;                    // [RING][WBUF]
+    unsigned char* const pbuf = smem + RING * WBUF;      // [2][NP*64]
+    constexpr int patch_bytes = NP * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % a.ntiles_n;
+    bid /= a.ntiles_n;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int nk = a.nchunks * 9;
+
+    // per-lane source pixel of each 64-pixel block (or -1: padding -> zero page)
+    int src_pix[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int pix = pb * 64 + lane;
+        const int py = pix / a.PW, px = pix - py * a.PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        src_pix[pb] = (py < a.PH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (n * a.H + iy) * a.W + ix : -1;
+    }
+    auto issue_p = [&](int chunk, auto pb_c) {
+        constexpr int pb = decltype(pb_c)::value;
+        const int c = chunk * 32;
+        const bool s0 = c < a.C0;
+        const uint16_t* src = s0 ? a.in0 : a.in1;
+        const int cs = s0 ? a.in0_cs : a.in1_cs;
+        const int cb = (s0 ? c : c - a.C0) + wave * 8;
+        const int sp = src_pix[pb];
+        const uint16_t* g = sp >= 0 ? src + (size_t)sp * cs + cb : (const uint16_t*)a.zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(pbuf + (chunk & 1) * patch_bytes + (wave * NP + pb * 64) * 16),
+                                         16, 0, 0);
+    };
+    const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
+    auto issue_w = [&](int ks, int slot) {
+#pragma unroll
+        for (int p0 = 0; p0 < WPIECES; p0 += NT)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
+                                             (__attribute__((address_space(3))) void*)(wbuf + slot * WBUF + (p0 + wave * 64) * 16), 16, 0, 0);
+    };
+    const int fpr = a.TW >> 4;
+    int frag_off[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int F = wm * MF + f;
+        const int fr = F / fpr, fc = F - fr * fpr;
+        frag_off[f] = (fr * a.PW + fc * 16) * 16;
+    }
+    const int lane_patch_off = ((lane >> 4) * NP + (lane & 15)) * 16;
+    const int lane_w_off = wn * 4 * 1024 + lane * 16;
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // patch DMA schedule inside a chunk: PCNT(tap) blocks at tap (first taps take two while NPB > PSLOTS)
+    struct Sched {
+        static constexpr int pcnt(int tap) { return tap >= PSLOTS ? 0 : ((NPB - PSLOTS > tap ? 2 : 1) * (tap < (NPB > PSLOTS ? PSLOTS : NPB) ? 1 : 0)); }
+        static constexpr int pfirst(int tap) { int s = 0; for (int t = 0; t < tap; ++t) s += pcnt(t); return s; }
+        static constexpr int wcnt(bool more, int tap) { return (more || tap < 9 - (RING - 1)) ? WPT : 0; }
+        // operations younger than slice ks+1 at the end of tap `tap` of a chunk of kind `more` (previous chunk: kind true)
+        static constexpr int younger(bool more, int tap) {
+            int nv = wcnt(more, tap) + (more ? pcnt(tap) : 0);
+            for (int back = 1; back <= RING - 2; ++back) {
+                const int t = tap - back;
+                const bool m = t >= 0 ? more : true;
+                const int tt = t >= 0 ? t : t + 9;
+                const int pc = m ? pcnt(tt) : 0;
+                nv += (back == RING - 2) ? pc : (wcnt(m, tt) + pc);   // the oldest k-step of the window: only what followed its slice
+            }
+            return nv;
+        }
+    };
+    static_assert(Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
+
+    // prologue: first RING-1 weight slices + the whole first patch
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (i < nk) issue_w(i, i);
+    [&]<int... PB>(std::integer_sequence<int, PB...>) { (issue_p(0, std::integral_constant<int, PB>{}), ...); }(std::make_integer_sequence<int, NPB>{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int wslot = 0, ks = 0;
+    auto step = [&](auto tap_c, auto more_c, int c) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
+        if constexpr (Sched::wcnt(MORE, tap) > 0) {
+            int slot = wslot + RING - 1;
+            if (slot >= RING) slot -= RING;
+            issue_w(ks + RING - 1, slot);
+        }
+        if constexpr (MORE && Sched::pcnt(tap) > 0) {
+            issue_p(c + 1, std::integral_constant<int, Sched::pfirst(tap)>{});
+            if constexpr (Sched::pcnt(tap) > 1) issue_p(c + 1, std::integral_constant<int, Sched::pfirst(tap) + 1>{});
+        }
+        constexpr int ky = tap / 3, kx = tap % 3;
+        const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
+        const unsigned char* pb = pbuf + (c & 1) * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
+        bf16x8 af[4], bq[MF];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+        if ((c * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
+        ++ks;
+        wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    };
+    auto chunk = [&](auto more_c, int c) {
+        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, 9>{});
+    };
+    for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
+    chunk(std::false_type{}, a.nchunks - 1);
+
+    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -372,9 +589,9 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
                 }
 }
 
-template <int WM, int WN, int MF, int PITER, bool PIPE>
+template <int WM, int WN, int MF, int PITER, int RING>
 static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
-    auto k = conv_mfma_kernel<WM, WN, MF, PITER, PIPE>;
+    auto k = conv_mfma_kernel<WM, WN, MF, PITER, RING>;
     static size_t cur = 0;   // per-instantiation high-water mark of the opt-in dynamic LDS size
     if (smem > cur) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -385,18 +602,53 @@ static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream
     return hipGetLastError();
 }
 
-static bool conv_pipelined() {   // BBOCR_CONV_PIPE=1 selects the software-pipelined schedule (A/B runs; measured 6 % slower)
-    static const bool v = [] { const char* e = getenv("BBOCR_CONV_PIPE"); return e && e[0] == '1'; }();
+static int conv_ring() {   // generic kernel: BBOCR_CONV_RING=3/4 selects the counted deep-ring schedule (A/B runs; measured slower
+                           // than the reference schedule because register-staged loads still drain at every store)
+    static const int v = [] { const char* e = getenv("BBOCR_CONV_RING"); const int r = e ? atoi(e) : 2; return r < 2 ? 2 : (r > 4 ? 4 : r); }();
     return v;
 }
 
-#define NP_TWO_PART(P) ((P) > 4)
 template <int WM, int WN, int MF, int PITER>
 static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
-    const bool pipe = conv_pipelined() && a.ntaps >= 3 && PITER <= 8;
-    const size_t smem = (size_t)(pipe ? 3 : 2) * WN * 64 * 64 + (size_t)2 * a.NP * 64;
+    constexpr int BNc = WN * 64;
+    const size_t patch = (size_t)2 * a.NP * 64;
+    if constexpr (WM * WN == 4) {   // 256-thread configs: counted schedule, deepest ring that still lets two workgroups share a CU
+        const int want = conv_ring();
+        if (want >= 4 && (size_t)4 * BNc * 64 + patch <= 80 * 1024) return launch_one<WM, WN, MF, PITER, 4>(a, (size_t)4 * BNc * 64 + patch, grid, s);
+        if (want >= 3 && (size_t)3 * BNc * 64 + patch <= 80 * 1024) return launch_one<WM, WN, MF, PITER, 3>(a, (size_t)3 * BNc * 64 + patch, grid, s);
+    }
+    const size_t smem = (size_t)2 * BNc * 64 + patch;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    return pipe ? launch_one<WM, WN, MF, PITER, true>(a, smem, grid, s) : launch_one<WM, WN, MF, PITER, false>(a, smem, grid, s);
+    return launch_one<WM, WN, MF, PITER, 2>(a, smem, grid, s);
+}
+
+static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 variant (A/B runs)
+    static const bool v = [] { const char* e = getenv("BBOCR_CONV_DMA"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+template <int WM, int WN, int MF, int NPB, int RING>
+static hipError_t launch_dma_one(const ConvArgs& a, int grid, hipStream_t s) {
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING>;
+    const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPB * 64 * 64;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
+    return hipGetLastError();
+}
+
+template <int WM, int WN, int MF>
+static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s) {
+    const size_t wb = (size_t)WN * 64 * 64, pb = (size_t)2 * npb * 64 * 64;
+    static const int ring_cap = [] { const char* e = getenv("BBOCR_DMA_RING"); return e ? atoi(e) : 4; }();
+    const bool r4 = ring_cap >= 4 && 4 * wb + pb <= 80 * 1024;      // deepest ring that still lets two workgroups share a CU
+    if (npb == 6) return r4 ? launch_dma_one<WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);
+    if (npb == 7) return launch_dma_one<WM, WN, MF, 7, 3>(a, grid, s);
+    return hipErrorInvalidValue;
 }
 
 static bool conv_small_wg() {   // BBOCR_CONV_WG=512 selects the original one-workgroup-per-CU configurations (A/B runs)
@@ -419,7 +671,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
-    const int ring = conv_pipelined() ? 3 : 2;
+    const int ring = 2;
     const int max_piter = small ? 16 : 8;
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
     {
@@ -446,9 +698,18 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     if ((a.in0_cs & 7) || (a.C1 && (a.in1_cs & 7)) || (a.out_cs & (a.out_f32 ? 3 : 7)) || (a.cout_store & 15)) return hipErrorInvalidValue;
     a.wpk = p.d_w;
     a.bias = p.d_b;
+    static const int dbg = [] { const char* e = getenv("BBOCR_CONV_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
+    if (small && conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
+        const int npb = cdiv(a.PH * a.PW, 64);
+        if (npb == 6 || npb == 7) {
+            a.NP = npb * 64;
+            return BN == 128 ? launch_dma<2, 2, 8>(a, npb, grid, s) : launch_dma<4, 1, 4>(a, npb, grid, s);
+        }
+    }
     const int piter = cdiv(a.NP / 16, NWV);
     if (small) {
         if (BN == 128) return piter <= 4 ? launch_cfg<2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<2, 2, 8, 8>(a, grid, s) : launch_cfg<2, 2, 8, 16>(a, grid, s));

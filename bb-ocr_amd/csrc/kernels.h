@@ -22,6 +22,8 @@ struct ConvArgs {
     // fused max-pool in the epilogue: 0 none, 1 = MaxPool2d(2,2), 2 = MaxPool2d((2,1),(2,1)); bf16 output [N,OH/2,OW(/2),pool_cs]
     int pool_mode, pool_relu, store_full, pool_cs;
     void* pool_out;
+    int dbg;               // timing-only ablation switches (BBOCR_CONV_DBG); 0 in production
+    const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
 };
 
 struct ConvPlan {      // host-side description of one packed conv layer
@@ -37,7 +39,7 @@ int conv_plan_bn(int Cout);   // cout tile (64/128/256) of the launch configurat
 size_t conv_packed_elems(const ConvPlan& p);
 // w: fp32 [Cout][Cin][KH][KW] already BN-folded; out: bf16 bits, layout [ntile][chunk][tap][frag][lane][8]
 void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out);
-hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);
+hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zero must be set (device zero page)
 
 // ------------------------------------------------------------------ detector front/back (craft_misc.hip)
 hipError_t launch_conv1_1(const uint8_t* rgb, int N, int Himg, int Wimg, int H32, int W32, const uint16_t* wpk, const float* bias,
