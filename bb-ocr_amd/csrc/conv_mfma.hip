@@ -561,6 +561,117 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
 }
 
+// ================================================================================================ 1x1, LDS-DMA staged
+// 1x1 convolutions (fc7, the U-net "concat + 1x1" layers, the LSTM input projections, the linear layers, the class
+// projection) are plain GEMMs over the flattened pixel axis: [pixels, Cin] x [Cin, Cout].  One k-step per 32-channel chunk;
+// BOTH operand tiles of k-step ks+RING-1 are issued by LDS-DMA at k-step ks (weights: lane-linear slice; activations: wave w
+// gathers channel group w of 256 consecutive pixels, 16 B per lane), and the barrier waits with the constant counted
+// vmcnt((RING-2) * DMAs-per-k-step).  No halo, so the tile is simply 256 consecutive pixels of N*H*W.
+template <int WM, int WN, int MF, int RING>
+__global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
+    static_assert(NW == 4, "one wave per 8-channel group of the activation tile");
+    constexpr int WBUF = BN * 64, WPIECES = WBUF / 16, WPT = WPIECES / NT;
+    constexpr int NPX = WM * MF * 16, NPB = NPX / 64, PBUF = NPX * 64, SLOT = WBUF + PBUF;
+    static_assert(WPIECES % NT == 0 && NPX % 64 == 0 && RING >= 3, "uniform DMA issue");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [RING][weights WBUF | activations PBUF]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % a.ntiles_n;
+    const int tile = bid / a.ntiles_n;
+    const int px0 = tile * NPX;                // first pixel of the tile in the flattened N*H*W axis (a.OW = total pixels)
+    const int nk = a.nchunks;
+    int pix[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int p = px0 + pb * 64 + lane;
+        pix[pb] = p < a.OW ? p : -1;
+    }
+    const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
+    auto issue = [&](int ks, int slot) {
+        unsigned char* sb = smem + slot * SLOT;
+#pragma unroll
+        for (int p0 = 0; p0 < WPIECES; p0 += NT)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
+                                             (__attribute__((address_space(3))) void*)(sb + (p0 + wave * 64) * 16), 16, 0, 0);
+        const int c = ks * 32;
+        const bool s0 = c < a.C0;
+        const uint16_t* src = s0 ? a.in0 : a.in1;
+        const int cs = s0 ? a.in0_cs : a.in1_cs;
+        const int cb = (s0 ? c : c - a.C0) + wave * 8;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const uint16_t* g = pix[pb] >= 0 ? src + (size_t)pix[pb] * cs + cb : (const uint16_t*)a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(sb + WBUF + (wave * NPX + pb * 64) * 16), 16, 0, 0);
+        }
+    };
+    const int lane_p_off = WBUF + ((lane >> 4) * NPX + (lane & 15)) * 16 + wm * MF * 256;
+    const int lane_w_off = wn * 4 * 1024 + lane * 16;
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (i < nk) issue(i, i);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int slot = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool ahead = ks + RING - 1 < nk;
+        if (ahead) {
+            int sl = slot + RING - 1;
+            if (sl >= RING) sl -= RING;
+            issue(ks + RING - 1, sl);
+        }
+        const unsigned char* sb = smem + slot * SLOT;
+        bf16x8 af[4], bq[MF];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(sb + lane_w_off + j * 1024);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(sb + lane_p_off + f * 256);
+        if ((ks * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+        // k-step ks+1 was issued RING-2 k-steps ago; while the pipeline is full exactly RING-2 later issues follow it
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 2) * (WPT + NPB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        slot = slot + 1 == RING ? 0 : slot + 1;
+    }
+    conv_epilogue<MF>(a, acc, 0, nt, 0, px0, wm, wn, 16, lane, BN);
+}
+
+template <int WM, int WN, int MF>
+static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
+    constexpr int RING = 3, NPX = WM * MF * 16;
+    const long long total = (long long)a.N * a.H * a.W;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.N = 1; a.OH = 1; a.OW = (int)total; a.TH = 1; a.TW = NPX; a.tiles_y = 1;
+    a.tiles_x = (int)((total + NPX - 1) / NPX);
+    const long long grid = (long long)a.tiles_x * a.ntiles_n;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    auto k = conv1x1_dma_kernel<WM, WN, MF, RING>;
+    const size_t smem = (size_t)RING * ((size_t)WN * 64 * 64 + (size_t)NPX * 64);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3((int)grid), dim3(WM * WN * 64), smem, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -703,6 +814,8 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
+    if (small && conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
+        return BN == 128 ? launch_dma1x1<2, 2, 8>(a, s) : launch_dma1x1<4, 1, 4>(a, s);
     if (small && conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
         const int npb = cdiv(a.PH * a.PW, 64);
         if (npb == 6 || npb == 7) {
