@@ -22,7 +22,7 @@
 // ---- shared epilogue: bias (+ReLU) (+fused max-pool); each lane owns 16 contiguous couts of its pixel per fragment
 template <int MF>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn, int fpr,
-                                              int lane, int BN) {
+                                              int lane, int BN, int sub = 1, int sph = 0, int spw = 0) {
     const int g = lane >> 4, pl = lane & 15;
     const int cout0 = nt * BN + wn * 64 + g * 16;
     if (cout0 >= a.cout_store) return;
@@ -50,7 +50,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
         for (int f = 0; f < MF; ++f) {
             const int F = wm * MF + f;
             const int fr = F / fpr, fc = F - fr * fpr;
-            const int oy = oy0 + fr, ox = ox0 + fc * 16 + pl;
+            // sub > 1: the tile lives on one phase (sph, spw) of the dilation lattice (dilated conv run as sub*sub plain convs)
+            const int oy = (oy0 + fr) * sub + sph, ox = (ox0 + fc * 16 + pl) * sub + spw;
             if (oy < a.OH && ox < a.OW) {
                 float v[16];
 #pragma unroll
@@ -441,7 +442,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
+    int n = bid / a.tiles_y;
+    // dilation d (a.sub) with padding d == d*d independent plain 3x3 convs on the phase sub-lattices: image index n' enumerates
+    // (n, phase_y, phase_x); tile coordinates are in sub-lattice units
+    const int sub = a.sub;
+    int sph = 0, spw = 0;
+    if (sub > 1) { spw = n % sub; n /= sub; sph = n % sub; n /= sub; }
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nk = a.nchunks * 9;
@@ -452,8 +458,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     for (int pb = 0; pb < NPB; ++pb) {
         const int pix = pb * 64 + lane;
         const int py = pix / a.PW, px = pix - py * a.PW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        src_pix[pb] = (py < a.PH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (n * a.H + iy) * a.W + ix : -1;
+        const int ly = iy0 + py, lx = ix0 + px;                 // sub-lattice coordinates
+        const int iy = ly * sub + sph, ix = lx * sub + spw;
+        src_pix[pb] = (py < a.PH && ly >= 0 && iy < a.H && lx >= 0 && ix < a.W) ? (n * a.H + iy) * a.W + ix : -1;
     }
     auto issue_p = [&](int chunk, auto pb_c) {
         constexpr int pb = decltype(pb_c)::value;
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
     chunk(std::false_type{}, a.nchunks - 1);
 
-    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
+    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN, sub, sph, spw);
 }
 
 // ================================================================================================ 1x1, LDS-DMA staged
@@ -782,6 +789,31 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
+    a.sub = 1;
+    if (small && conv_dma() && a.zero && !a.pool_mode && p.KH == 3 && p.KW == 3 && p.dil > 1 && p.pad_h == p.dil && p.pad_w == p.dil) {
+        const int d = p.dil, LH = cdiv(a.OH, d), LW = cdiv(a.OW, d);   // phase sub-lattice size
+        long long best = -1;
+        for (int th = 16; th >= 4; th >>= 1) {
+            const int tw = 256 / th, ph = th + 2, pw = tw + 2, npb = cdiv(ph * pw, 64);
+            if (npb != 6 && npb != 7) continue;
+            const long long cost = (long long)cdiv(LH, th) * cdiv(LW, tw);
+            if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = npb * 64; }
+        }
+        if (best > 0 && (a.C0 + a.C1 == p.Cin_pad) && !(a.C0 & 31) && !(a.C1 & 31)) {
+            a.sub = d;
+            a.tiles_x = cdiv(LW, a.TW);
+            a.tiles_y = cdiv(LH, a.TH);
+            a.ntiles_n = p.Cout_pad / BN;
+            a.nchunks = p.Cin_pad / 32;
+            a.wpk = p.d_w;
+            a.bias = p.d_b;
+            a.dbg = 0;
+            const long long g = (long long)a.N * d * d * a.tiles_x * a.tiles_y * a.ntiles_n;
+            if (g > 0 && g <= 0x7fffffffLL)
+                return BN == 128 ? launch_dma<2, 2, 8>(a, a.NP / 64, (int)g, s) : launch_dma<4, 1, 4>(a, a.NP / 64, (int)g, s);
+            a.sub = 1;
+        }
+    }
     const int ring = 2;
     const int max_piter = small ? 16 : 8;
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer

@@ -23,6 +23,7 @@ struct ConvArgs {
     int pool_mode, pool_relu, store_full, pool_cs;
     void* pool_out;
     int dbg;               // timing-only ablation switches (BBOCR_CONV_DBG); 0 in production
+    int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
 };
 
