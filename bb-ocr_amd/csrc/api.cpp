@@ -277,7 +277,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
             const float* bhh = tm.get(sm + "rnn.bias_hh_l0" + sfx, 1024);
             for (int g = 0; g < 4; ++g)
                 for (int u = 0; u < 256; ++u) {
-                    const int src = g * 256 + u, dst = lstm_xproj_channel(d, g, u);
+                    const int src = g * 256 + u, dst = lstm_variant() == 8 ? lstm8_xproj_channel(d, g, u) : lstm_xproj_channel(d, g, u);
                     std::copy(wih + (size_t)src * 256, wih + (size_t)src * 256 + 256, w.begin() + (size_t)dst * 256);
                     b[dst] = bih[src] + bhh[src];
                 }
@@ -287,7 +287,8 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         const float* hf = tm.get(sm + "rnn.weight_hh_l0", (size_t)1024 * 256);
         const float* hb = tm.get(sm + "rnn.weight_hh_l0_reverse", (size_t)1024 * 256);
         std::vector<uint16_t> pk(lstm_whh_packed_elems());
-        pack_lstm_whh(hf, hb, pk.data());
+        if (lstm_variant() == 8) pack_lstm_whh8(hf, hb, pk.data());
+        else pack_lstm_whh(hf, hb, pk.data());
         c->whh[l] = upload(c, pk);
         std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
         std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);

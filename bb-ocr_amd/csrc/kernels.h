@@ -90,6 +90,9 @@ hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* 
 void pack_lstm_whh(const float* whh_fwd /*[1024][256]*/, const float* whh_bwd, uint16_t* out);
 size_t lstm_whh_packed_elems();
 int lstm_xproj_channel(int dir, int gate, int unit);
+int lstm_variant();   // 8 (default) or 4 waves per workgroup; selects packing + channel permutation
+void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out);
+int lstm8_xproj_channel(int dir, int gate, int unit);
 struct CtcOut { int len; int cnt; float prod; int pad; };
 // seqs_dev: int2 per sequence {first row, T}; logits fp32 [rows, cs]; out_idx is row-indexed like the pool
 hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,

@@ -11,6 +11,7 @@
 // c stays in fp32 registers for all T steps; h crosses LDS as bf16 (it is the next step's A operand).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
@@ -178,8 +179,149 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
     }
 }
 
+// ================================================================================================ 8-wave variant
+// Same recurrence, eight waves per workgroup (two per SIMD): wave w owns hidden units [32w, 32w+32) = two 16-unit groups,
+// 64 MFMAs per step.  Two waves share a SIMD, so one wave's lane-local gate math (transcendental-bound) overlaps the
+// other's MFMA stream; per-step critical path ~ the MFMA floor (128 MFMAs per SIMD) instead of MFMA + VALU in series.
+// Weight residency per wave (64 fragments): LSTM8_NR in registers, LSTM8_NL in LDS, the rest streamed from L2.
+// Packed layout [dir][wave 8][group 2][kk 8][gate 4][lane 64][8]; input-projection channels permuted so that a lane's 8
+// gate pre-activations of one sequence are 16 contiguous bytes (lstm8_xproj_channel).
+#define LSTM8_NR 28
+#define LSTM8_NL 18
+void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
+    size_t o = 0;
+    for (int d = 0; d < 2; ++d) {
+        const float* W = d ? whh_bwd : whh_fwd;
+        for (int w = 0; w < 8; ++w)
+            for (int a = 0; a < 2; ++a)
+                for (int kk = 0; kk < 8; ++kk)
+                    for (int gate = 0; gate < 4; ++gate)
+                        for (int l = 0; l < 64; ++l) {
+                            const int unit = w * 32 + a * 16 + (l & 15);
+                            const int row = gate * 256 + unit;
+                            for (int j = 0; j < 8; ++j) out[o++] = f32_to_bf16_host(W[(size_t)row * 256 + kk * 32 + 8 * (l >> 4) + j]);
+                        }
+    }
+}
+int lstm8_xproj_channel(int dir, int gate, int unit) {
+    return dir * 1024 + (((unit >> 5) * 16 + (unit & 15)) * 8) + ((unit >> 4) & 1) * 4 + gate;
+}
+
+__global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
+                                                       uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
+    unsigned char (*hbuf)[32 * 16 * 16] = (unsigned char (*)[32 * 16 * 16])lstm_smem;   // [2][kgroup 32][seq 16] x 16 B
+    unsigned char* const wlds = lstm_smem + 2 * 32 * 16 * 16;                             // [wave 8][LSTM8_NL][lane 64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int4 tile = tiles[blockIdx.x];
+    const int row0 = tile.x, n = tile.y, T = tile.z;
+    const int g = lane >> 4, u = lane & 15;
+    for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 512) ((u32x4*)lstm_smem)[i] = (u32x4){0u, 0u, 0u, 0u};
+    float c[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
+    const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane;
+    bf16x8 wreg[LSTM8_NR];
+#pragma unroll
+    for (int i = 0; i < LSTM8_NR; ++i) wreg[i] = wv0[(size_t)i * 64];
+    bf16x8* const wl = (bf16x8*)(wlds + (size_t)wave * LSTM8_NL * 1024) + lane;
+#pragma unroll 2
+    for (int i = 0; i < LSTM8_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(LSTM8_NR + i) * 64];
+    const int xch = dir * 1024 + (wave * 16 + u) * 8;
+    const int wb_seq = tid >> 5, wb_kg = tid & 31;   // h write-back: 16 B per thread
+    auto load_x = [&](int step, u32x4 (&xq)[4]) {
+        const int t = dir ? (T - 1 - step) : step;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = g * 4 + r;
+            if (s < n && step < T) xq[r] = *(const u32x4*)(xproj + ((size_t)row0 + (size_t)s * T + t) * 2048 + xch);
+            else xq[r] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    u32x4 xq[4], xn[4];
+    load_x(0, xq);
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        load_x(step + 1, xn);
+        const unsigned char* hb = hbuf[cur];
+        unsigned char* hn = hbuf[cur ^ 1];
+        const bf16x8* wv = wv0;
+        asm volatile("" : "+v"(wv));     // keep the streamed fragment loads inside the time loop
+        bf16x8 af[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) af[kk] = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
+        f32x4 acc[2][4];
+        auto mfma_group = [&](auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int fi = a * 32 + kk * 4 + q;
+                    bf16x8 bfr;
+                    if (fi < LSTM8_NR) bfr = wreg[fi < LSTM8_NR ? fi : 0];
+                    else if (fi < LSTM8_NR + LSTM8_NL) bfr = wl[(size_t)(fi - LSTM8_NR) * 64];
+                    else bfr = wv[(size_t)fi * 64];
+                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[a][q], 0, 0, 0);
+                }
+        };
+        auto gate_group = [&](auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+            const int unit = wave * 32 + a * 16 + u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned int w0 = xq[r][a * 2], w1 = xq[r][a * 2 + 1];
+                const float gi = acc[a][0][r] + __uint_as_float(w0 << 16);
+                const float gf = acc[a][1][r] + __uint_as_float(w0 & 0xffff0000u);
+                const float gg = acc[a][2][r] + __uint_as_float(w1 << 16);
+                const float go = acc[a][3][r] + __uint_as_float(w1 & 0xffff0000u);
+                const float cn = sigmoid_f(gf) * c[a][r] + sigmoid_f(gi) * tanh_f(gg);
+                c[a][r] = cn;
+                const float hv = sigmoid_f(go) * tanh_f(cn);
+                *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
+            }
+        };
+        mfma_group(std::integral_constant<int, 0>{});
+        mfma_group(std::integral_constant<int, 1>{});
+        gate_group(std::integral_constant<int, 0>{});
+        gate_group(std::integral_constant<int, 1>{});
+        __syncthreads();
+        if (wb_seq < n) {
+            const u32x4 h0 = *(const u32x4*)(hn + (wb_kg * 16 + wb_seq) * 16);
+            *(u32x4*)(out + ((size_t)row0 + (size_t)wb_seq * T + t) * 512 + dir * 256 + wb_kg * 8) = h0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xq[r] = xn[r];
+        cur ^= 1;
+    }
+}
+
+int lstm_variant() {   // BBOCR_LSTM=4 selects the 4-wave kernel (A/B runs); default: 8-wave kernel
+    static const int v = [] { const char* e = getenv("BBOCR_LSTM"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    return v;
+}
+
 hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
+    if (lstm_variant() == 8) {
+        const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
+        static bool attr8 = false;
+        if (!attr8) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+            if (e != hipSuccess) return e;
+            attr8 = true;
+        }
+        hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev);
+        return hipGetLastError();
+    }
     const size_t smem = 2 * 32 * 16 * 16 + (size_t)4 * LSTM_NL * 1024;
     static bool attr_set = false;
     if (!attr_set) {
