@@ -496,31 +496,30 @@ struct HostBoxes {
 static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double ratio, const bbocr_params& p, HostBoxes& hb) {
     if (B <= 0 || h <= 0 || w <= 0 || !(ratio > 0)) fail(BBOCR_ERR_ARG, "bad heat-map shape");
     const size_t npx = (size_t)B * h * w;
-    const int cap_comps = std::max(1024, h * w / 64), cap_rows = std::max(4096, h * w / 4);
+    const int cap_comps = (int)std::min<size_t>(0x3fffffff, (size_t)B * std::max(1024, h * w / 64));
+    const int cap_rows = (int)std::min<size_t>(0x3fffffff, (size_t)B * std::max(4096, h * w / 4));
     c->ccl_label.ensure(npx * 4);
     c->ccl_stat.ensure(npx * 24);
     c->ccl_slot.ensure(npx * 4);
-    c->ccl_comps.ensure((size_t)B * cap_comps * sizeof(CclOut));
-    c->ccl_rowext.ensure((size_t)B * cap_rows * 8);
-    c->ccl_counters.ensure((size_t)B * 16);
+    c->ccl_comps.ensure((size_t)cap_comps * sizeof(CclOut));
+    c->ccl_rowext.ensure((size_t)cap_rows * 8);
+    c->ccl_counters.ensure(16);
     auto t0 = clk::now();
     HIPCHK(launch_ccl(heat, B, h, w, (float)p.low_text, (float)p.link_threshold, (double)p.text_threshold, (int*)c->ccl_label.p,
                       (int*)c->ccl_stat.p, (int*)c->ccl_slot.p, (CclOut*)c->ccl_comps.p, (int*)c->ccl_rowext.p, (int*)c->ccl_counters.p,
                       cap_comps, cap_rows, c->stream));
-    std::vector<int> counters((size_t)B * 4);
-    HIPCHK(hipMemcpyAsync(counters.data(), c->ccl_counters.p, counters.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    int counters[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(counters, c->ccl_counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (counters[2]) fail(BBOCR_ERR_OVERFLOW, "component buffers too small for this batch");
+    std::vector<CclOut> all_comps(counters[0]);
+    std::vector<int> all_rows((size_t)counters[1] * 2);
+    if (counters[0]) HIPCHK(hipMemcpyAsync(all_comps.data(), c->ccl_comps.p, all_comps.size() * sizeof(CclOut), hipMemcpyDeviceToHost, c->stream));
+    if (counters[1]) HIPCHK(hipMemcpyAsync(all_rows.data(), c->ccl_rowext.p, all_rows.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<std::vector<CclOut>> comps(B);
-    std::vector<std::vector<int>> rows(B);
-    for (int b = 0; b < B; ++b) {
-        if (counters[b * 4 + 2]) fail(BBOCR_ERR_OVERFLOW, "component buffers too small for page " + std::to_string(b));
-        const int nc = counters[b * 4], nr = counters[b * 4 + 1];
-        comps[b].resize(nc);
-        rows[b].resize((size_t)nr * 2);
-        if (nc) HIPCHK(hipMemcpyAsync(comps[b].data(), (CclOut*)c->ccl_comps.p + (size_t)b * cap_comps, nc * sizeof(CclOut), hipMemcpyDeviceToHost, c->stream));
-        if (nr) HIPCHK(hipMemcpyAsync(rows[b].data(), (int*)c->ccl_rowext.p + (size_t)b * cap_rows * 2, (size_t)nr * 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (const CclOut& co : all_comps)
+        if (co.img >= 0 && co.img < B) comps[co.img].push_back(co);
     c->times[1] += (float)ms_since(t0);
     t0 = clk::now();
     const double ratio_w = 1.0 / ratio, ratio_h = 1.0 / ratio;
@@ -534,7 +533,7 @@ static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, dou
         for (const CclOut& co : comps[b]) {
             bbocr::Component cc{co.root, co.left, co.top, co.right, co.bottom, co.area, co.row_off};
             float box[4][2];
-            bbocr::component_box(cc, rows[b].data() + (size_t)co.row_off * 2, w, h, box);
+            bbocr::component_box(cc, all_rows.data() + (size_t)co.row_off * 2, w, h, box);
             std::array<int, 8> poly;
             bbocr::box_to_poly(box, ratio_w, ratio_h, poly.data());
             hb.polys[b].push_back(poly);

@@ -51,22 +51,52 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(size_t total, int h, int
     }
 }
 
+// Flatten + per-component statistics.  A wave covers 64 consecutive pixels of the flattened image; lanes that continue the
+// previous lane's component in the same row form a run, and only the run's first lane touches the component's counters
+// (area = run length, x extremes = run ends, max text score by a segmented shuffle reduction): ~10x fewer atomics than
+// one set per foreground pixel.
 __global__ void __launch_bounds__(256) ccl_stats_kernel(const float* __restrict__ heat, size_t total, int h, int w, int* label,
                                                         int* __restrict__ stat) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        if (label[i] < 0) continue;
-        const int r = ccl_find(label, (int)i);
-        label[i] = r;
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        int* st = stat + (size_t)r * 6;
-        atomicMin(st + 0, x);
-        atomicMax(st + 1, x);
-        atomicMin(st + 2, y);
-        atomicMax(st + 3, y);
-        atomicAdd(st + 4, 1);
-        const float t = heat[i * 2];
-        if (t > 0.f) atomicMax(st + 5, __float_as_int(t));
+    const int lane = threadIdx.x & 63;
+    const size_t nround = (total + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    for (size_t it = 0; it < nround; ++it) {
+        const size_t i = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        int r = -1, x = 0, y = 0;
+        float t = 0.f;
+        if (i < total && label[i] >= 0) {
+            r = ccl_find(label, (int)i);
+            label[i] = r;
+            x = (int)(i % w);
+            y = (int)((i / w) % h);
+            t = fmaxf(heat[i * 2], 0.f);
+        }
+        const int rp = __shfl_up(r, 1);
+        const bool head = r >= 0 && (lane == 0 || rp != r || x == 0);      // a run never crosses a row (or image) boundary
+        const unsigned long long hm = __ballot(head || r < 0);              // run breaks: heads and background lanes
+        if (r >= 0) {
+            // run = [first break at or below lane, next break above lane)
+            const unsigned long long below = hm & ((lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL));
+            const int first = 63 - __clzll((long long)below);
+            const unsigned long long above = (lane == 63) ? 0ULL : (hm >> (lane + 1));
+            const int len_after = above ? (__ffsll((long long)above) - 1) : (63 - lane);   // lanes of this run after me
+            // segmented max of the text score over the run (suffix max towards the head)
+            float m = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float mo = __shfl_down(m, o);
+                if (o <= len_after) m = fmaxf(m, mo);
+            }
+            if (head) {
+                int* st = stat + (size_t)r * 6;
+                atomicMin(st + 0, x);
+                atomicMax(st + 1, x + len_after);
+                atomicMin(st + 2, y);
+                atomicMax(st + 3, y);
+                atomicAdd(st + 4, len_after + 1);
+                if (m > 0.f) atomicMax(st + 5, __float_as_int(m));
+            }
+            (void)first;
+        }
     }
 }
 
@@ -81,17 +111,16 @@ __global__ void __launch_bounds__(256) ccl_accept_kernel(size_t total, int hw, d
         // upstream compares the float32 maximum with the Python float 0.7 in double precision
         if ((double)__int_as_float(st[5]) < text_thr) continue;
         const int img = (int)(i / hw);
-        int* cnt = counters + img * 4;
         const int hh = st[3] - st[2] + 1;
-        const int idx = atomicAdd(cnt + 0, 1);
-        const int off = atomicAdd(cnt + 1, hh);
-        if (idx >= cap_comps || off + hh > cap_rows) { atomicOr(cnt + 2, 1); continue; }
+        const int idx = atomicAdd(counters + 0, 1);          // one compact list for the whole batch (single D2H copy)
+        const int off = atomicAdd(counters + 1, hh);
+        if (idx >= cap_comps || off + hh > cap_rows) { atomicOr(counters + 2, 1); continue; }
         CclOut c;
         c.root = (int)(i - (size_t)img * hw);
-        c.left = st[0]; c.top = st[2]; c.right = st[1]; c.bottom = st[3]; c.area = area; c.row_off = off; c.pad = 0;
-        comps[(size_t)img * cap_comps + idx] = c;
+        c.left = st[0]; c.top = st[2]; c.right = st[1]; c.bottom = st[3]; c.area = area; c.row_off = off; c.img = img;
+        comps[idx] = c;
         slot[i] = idx;
-        int* re = rowext + ((size_t)img * cap_rows + off) * 2;
+        int* re = rowext + (size_t)off * 2;
         for (int k = 0; k < hh; ++k) { re[2 * k] = 0x7fffffff; re[2 * k + 1] = -1; }
     }
 }
@@ -106,11 +135,10 @@ __global__ void __launch_bounds__(256) ccl_rowext_kernel(const float* __restrict
         if (!(heat[i * 2] > low_text)) continue;   // link-only pixels are removed from the segmentation map
         const int s = slot[r];
         if (s < 0) continue;
-        const int img = (int)(i / hw);
-        const CclOut c = comps[(size_t)img * cap_comps + s];
+        const CclOut c = comps[s];
         const int x = (int)(i % w);
         const int y = (int)((i / w) % h);
-        int* re = rowext + ((size_t)img * cap_rows + c.row_off + (y - c.top)) * 2;
+        int* re = rowext + ((size_t)c.row_off + (y - c.top)) * 2;
         atomicMin(re, x);
         atomicMax(re + 1, x);
     }
@@ -122,7 +150,7 @@ hipError_t launch_ccl(const float* heat, int N, int h, int w, float low_text, fl
     if (total == 0) return hipSuccess;
     if (total > 0x7fffffffULL) return hipErrorInvalidValue;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4 * N, s);
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, heat, total, low_text, link_thr, label, stat, slot);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid), dim3(256), 0, s, total, h, w, label);

@@ -56,9 +56,9 @@ hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, ui
 
 // ------------------------------------------------------------------ box extraction (ccl.hip)
 struct CclOut {        // per accepted component, device-written, host-sorted by root
-    int root, left, top, right, bottom, area, row_off, pad;
+    int root, left, top, right, bottom, area, row_off, img;
 };
-// label/slot: [N*h*w]; stat: [N*h*w][6]; comps: [N][cap_comps]; rowext: [N][cap_rows][2]; counters: [N][4] = ncomps, nrows, overflow
+// label/slot: [N*h*w]; stat: [N*h*w][6]; comps: [cap_comps] and rowext: [cap_rows][2] for the WHOLE batch; counters: [4] = ncomps, nrows, overflow
 hipError_t launch_ccl(const float* heat, int N, int h, int w, float low_text, float link_thr, double text_thr, int* label, int* stat,
                       int* slot, CclOut* comps, int* rowext, int* counters, int cap_comps, int cap_rows, hipStream_t s);
 

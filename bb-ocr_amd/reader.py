@@ -151,19 +151,27 @@ class Reader:
         return t
 
     def _collect(self, res_p, detail=1):
+        """bbocr_result -> per-page [(bbox, text, conf)] (upstream's list shape); numpy views instead of per-element ctypes access."""
         r = res_p.contents
         out = []
         try:
-            for b in range(r.n_images):
+            B = r.n_images
+            box_off = np.ctypeslib.as_array(r.box_off, shape=(B + 1,)).tolist()
+            nb = box_off[-1]
+            if nb:
+                quads = np.ctypeslib.as_array(r.quads, shape=(nb, 8))
+                is_free = np.ctypeslib.as_array(r.is_free, shape=(nb,)).tolist()
+                text_off = np.ctypeslib.as_array(r.text_off, shape=(nb + 1,)).tolist()
+                conf = np.ctypeslib.as_array(r.conf, shape=(nb,)).tolist()
+                nt = text_off[-1]
+                chars = np.array(CHARACTER, dtype=object)[np.ctypeslib.as_array(r.text_idx, shape=(max(nt, 1),))[:nt]] if nt else []
+                qi = quads.astype(np.int64).reshape(nb, 4, 2).tolist()
+                qf = quads.reshape(nb, 4, 2).tolist()
+            for b in range(B):
                 page = []
-                for i in range(r.box_off[b], r.box_off[b + 1]):
-                    q = [r.quads[i * 8 + k] for k in range(8)]
-                    if r.is_free[i]:
-                        box = [[q[0], q[1]], [q[2], q[3]], [q[4], q[5]], [q[6], q[7]]]
-                    else:
-                        box = [[int(q[0]), int(q[1])], [int(q[2]), int(q[3])], [int(q[4]), int(q[5])], [int(q[6]), int(q[7])]]
-                    text = "".join(CHARACTER[r.text_idx[k]] for k in range(r.text_off[i], r.text_off[i + 1]))
-                    page.append((box, text, float(r.conf[i])))
+                for i in range(box_off[b], box_off[b + 1]):
+                    box = qf[i] if is_free[i] else qi[i]
+                    page.append((box, "".join(chars[text_off[i]:text_off[i + 1]]), conf[i]))
                 out.append(page)
         finally:
             self._lib.bbocr_free_result(res_p)
