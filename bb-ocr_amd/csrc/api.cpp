@@ -97,7 +97,8 @@ struct bbocr_ctx {
     float* c11_b = nullptr;
     ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
     ConvPlan up1a, up1b, up2a, up2b, up3a, up3b, up4a, up4b, cls0, cls2, cls4;
-    float* cls_tail = nullptr;   // w1[256] b1[16] w2[32] b2[2]
+    float* cls_tail = nullptr;   // b1[16] w2[32] b2[2]
+    uint16_t* cls_tail_frag = nullptr;   // conv_cls.6 weight as an MFMA A fragment
     // ---- recogniser
     bool crnn_loaded = false;
     float* r0_wb = nullptr;      // w[32*9] b[32]
@@ -236,16 +237,22 @@ static void load_craft(bbocr_ctx* c, const TensorMap& tm) {
     load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
     load_layer(c, tm, c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1);
     {
-        std::vector<float> t(256 + 16 + 32 + 2);
         const float* w1 = tm.get("conv_cls.6.weight", 256);
         const float* b1 = tm.get("conv_cls.6.bias", 16);
         const float* w2 = tm.get("conv_cls.8.weight", 32);
         const float* b2 = tm.get("conv_cls.8.bias", 2);
-        std::copy(w1, w1 + 256, t.begin());
-        std::copy(b1, b1 + 16, t.begin() + 256);
-        std::copy(w2, w2 + 32, t.begin() + 272);
-        std::copy(b2, b2 + 2, t.begin() + 304);
+        std::vector<float> t(50);
+        std::copy(b1, b1 + 16, t.begin());
+        std::copy(w2, w2 + 32, t.begin() + 16);
+        std::copy(b2, b2 + 2, t.begin() + 48);
         c->cls_tail = upload(c, t);
+        std::vector<uint16_t> fr(64 * 8);
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int o = l & 15, k = 8 * (l >> 4) + j;
+                fr[l * 8 + j] = f32_to_bf16_host(k < 16 ? w1[o * 16 + k] : 0.f);
+            }
+        c->cls_tail_frag = upload(c, fr);
     }
     c->craft_loaded = true;
 }
@@ -431,10 +438,14 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     Act u4b = conv_act(c, c->up4b, u4a, false, nullptr, false, true, 32);
     Act c1 = conv_act(c, c->cls0, u4b, false, nullptr, false, true, 32);
     Act c2 = conv_act(c, c->cls2, c1, false, nullptr, false, true, 32);
-    Act c3 = conv_act(c, c->cls4, c2, false, nullptr, false, true, 16);
-    if (!ar.dry)
-        HIPCHK(launch_cls_tail(c3.p, c->cls_tail, c->cls_tail + 256, c->cls_tail + 272, c->cls_tail + 304, heat,
-                               (size_t)nb * c3.H * c3.W, c->stream));
+    // conv_cls.4 (3x3 32->16 + ReLU) with conv_cls.6/.8 fused into its epilogue: writes the fp32 heat-map directly
+    if (!ar.dry) {
+        ConvArgs a{};
+        a.in0 = c2.p; a.C0 = c2.C; a.in0_cs = c2.C;
+        a.N = c2.N; a.H = c2.H; a.W = c2.W;
+        a.relu_out = 1; a.out = heat; a.out_cs = 16; a.cout_store = 16; a.tail = c->cls_tail; a.tail_frag = c->cls_tail_frag;
+        launch_conv_profiled(c, c->cls4, a);
+    }
 }
 
 struct DetDims {

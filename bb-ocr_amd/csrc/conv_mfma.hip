@@ -25,6 +25,52 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                                               int lane, int BN, int sub = 1, int sph = 0, int spw = 0) {
     const int g = lane >> 4, pl = lane & 15;
     const int cout0 = nt * BN + wn * 64 + g * 16;
+    if (a.tail) {
+        // CRAFT classifier tail fused behind conv_cls.4 (3x3 32->16 + ReLU): conv_cls.6 (1x1 16->16 + ReLU) as ONE MFMA per
+        // fragment, conv_cls.8 (1x1 16->2) as 8 FMAs + a cross-group shuffle reduction; fp32 heat-map [N,h,w,2] out.
+        // Lane group 0 holds the 16 real channels of its pixel; a.tail = {b1[16], w2[32], b2[2]} fp32, a.tail_frag = W1 as
+        // an MFMA A fragment (row = out channel, k = in channel, zero beyond 16).
+        const float* tw = a.tail;
+        const bf16x8 w1f = *(const bf16x8*)(a.tail_frag + lane * 8);
+        float cb[16], b1r[4], w2a[4], w2b[4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cb[i] = a.bias[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b1r[r] = tw[4 * g + r]; w2a[r] = tw[16 + 4 * g + r]; w2b[r] = tw[32 + 4 * g + r]; }
+        const float b20 = tw[48], b21 = tw[49];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int F = wm * MF + f;
+            const int fr = F / fpr, fc = F - fr * fpr;
+            const int oy = (oy0 + fr) * sub + sph, ox = (ox0 + fc * 16 + pl) * sub + spw;
+            unsigned int pk[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = fmaxf(acc[f][j][0] + cb[j * 4 + 0], 0.f), x1 = fmaxf(acc[f][j][1] + cb[j * 4 + 1], 0.f);
+                const float x2 = fmaxf(acc[f][j][2] + cb[j * 4 + 2], 0.f), x3 = fmaxf(acc[f][j][3] + cb[j * 4 + 3], 0.f);
+                pk[2 * j] = pack_bf16x2(x0, x1);
+                pk[2 * j + 1] = pack_bf16x2(x2, x3);
+            }
+            u32x4 bb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned int hi = __shfl(pk[4 + i], pl);          // channels 8..15 of this pixel live in lane group 0
+                bb[i] = g == 0 ? pk[i] : (g == 1 ? hi : 0u);
+            }
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, __builtin_bit_cast(bf16x8, bb), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hv = fmaxf(d[r] + b1r[r], 0.f);
+                p0 = fmaf(w2a[r], hv, p0);
+                p1 = fmaf(w2b[r], hv, p1);
+            }
+            p0 += __shfl_xor(p0, 16); p1 += __shfl_xor(p1, 16);
+            p0 += __shfl_xor(p0, 32); p1 += __shfl_xor(p1, 32);
+            if (g == 0 && oy < a.OH && ox < a.OW) *(float2*)((float*)a.out + ((size_t)(n * a.OH + oy) * a.OW + ox) * 2) = make_float2(p0 + b20, p1 + b21);
+        }
+        return;
+    }
     if (cout0 >= a.cout_store) return;
     float bs[16];
 #pragma unroll

@@ -1,5 +1,5 @@
 // Detector-side kernels that are not the generic implicit-GEMM conv: fused normalise+conv1_1, max-pool,
-// bilinear x2 up-sampling, the tiny 1x1 classifier tail, gray conversion and the cv2-style uint8 bilinear resize.
+// bilinear x2 up-sampling, gray conversion and the cv2-style uint8 bilinear resize.
 // Upstream stages restated: easyocr/imgproc.py::{resize_aspect_ratio,normalizeMeanVariance}, craft.py::CRAFT.forward,
 // utils.py::reformat_input (reference call site pipeline_demo/extractor/enhanced_extractor.py:520).
 #include "common.h"
@@ -199,42 +199,6 @@ hipError_t launch_upsample2x(const uint16_t* in, uint16_t* out, int N, int H, in
     const size_t total = (size_t)N * 4 * H * W * (C / 8);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, in, out, N, H, W, C / 8);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------ classifier tail
-// conv_cls.6 (1x1 16->16)+ReLU, conv_cls.8 (1x1 16->2): one pixel per thread, weights in SGPR/const cache, fp32 math.
-__global__ void __launch_bounds__(256) cls_tail_kernel(const uint16_t* __restrict__ in, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ out, size_t npix) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-        const u32x4 a = *(const u32x4*)(in + i * 16);
-        const u32x4 b = *(const u32x4*)(in + i * 16 + 8);
-        float x[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[2 * j] = bf16lo(a[j]); x[2 * j + 1] = bf16hi(a[j]);
-            x[8 + 2 * j] = bf16lo(b[j]); x[8 + 2 * j + 1] = bf16hi(b[j]);
-        }
-        float o0 = b2[0], o1 = b2[1];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            float h = b1[o];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) h = fmaf(w1[o * 16 + k], x[k], h);
-            // the reference stores this activation in fp32; keep it fp32 here (0.02 % of the FLOPs)
-            h = fmaxf(h, 0.f);
-            o0 = fmaf(w2[o], h, o0);
-            o1 = fmaf(w2[16 + o], h, o1);
-        }
-        *(float2*)(out + i * 2) = make_float2(o0, o1);
-    }
-}
-
-hipError_t launch_cls_tail(const uint16_t* in, const float* w1, const float* b1, const float* w2, const float* b2, float* out, size_t npix,
-                           hipStream_t s) {
-    const int grid = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
-    hipLaunchKernelGGL(cls_tail_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, in, w1, b1, w2, b2, out, npix);
     return hipGetLastError();
 }
 

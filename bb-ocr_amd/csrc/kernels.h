@@ -23,6 +23,9 @@ struct ConvArgs {
     int pool_mode, pool_relu, store_full, pool_cs;
     void* pool_out;
     int dbg;               // timing-only ablation switches (BBOCR_CONV_DBG); 0 in production
+    const float* tail;     // non-null: fuse the CRAFT classifier tail (two 1x1 convs on 16 channels) into the epilogue (BN=64 config,
+                           // cout_store 16): {b1[16], w2[32], b2[2]}; tail_frag: W1 as a bf16 MFMA A fragment [64 lanes][8]
+    const uint16_t* tail_frag;
     int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
 };
@@ -49,8 +52,6 @@ void pack_conv1_1_weights(const float* w /*[64][3][3][3] folded*/, uint16_t* out
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
 hipError_t launch_upsample2x(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t s);
-hipError_t launch_cls_tail(const uint16_t* in, const float* w1, const float* b1, const float* w2, const float* b2, float* out, size_t npix,
-                           hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
 hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw, hipStream_t s);
 
