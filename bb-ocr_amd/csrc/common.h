@@ -32,8 +32,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN preserved)
     return __builtin_bit_cast(unsigned short, b);
 }
-__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (RNE, same rounding as the scalar cast)
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so

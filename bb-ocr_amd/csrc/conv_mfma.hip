@@ -8,33 +8,39 @@
 //   A = weights   [16 couts][32 k]   lane l: row l&15, k = 8(l>>4)+j      (LDS image == global packed image, glds copy)
 //   B = activation[32 k][16 pixels]  lane l: pixel l&15, k = 8(l>>4)+j    (LDS patch [4 channel-groups][NP pixels] x 16 B)
 //   D             [16 couts][16 px]  lane l: pixel l&15, couts 4(l>>4)+r  -> cout permutation in the packed weights makes
-//                                     each lane own 16 CONTIGUOUS couts of one pixel: 2 x 16-B NHWC stores per fragment.
+//                                     each lane own two runs of 8 contiguous couts: per store instruction the four lane
+//                                     groups of a pixel write 64 contiguous bytes (see conv_epilogue).
 // The activation patch (tile + halo) of one 32-channel chunk is staged once and re-read for all KHxKW taps; weights of
 // one (chunk, tap) k-step stream through a 2-deep LDS ring via LDS-DMA.  One workgroup = WM x WN waves, wave tile =
 // (MF*16 pixels) x 64 couts.  Launch grid is XCD-remapped so the cout tiles of one pixel tile share an L2.
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include <utility>
 
-// ---- shared epilogue: bias (+ReLU) (+fused max-pool); each lane owns 16 contiguous couts of its pixel per fragment
+// ---- shared epilogue: bias (+ReLU) (+fused max-pool).  Lane (pixel pl, group g) holds, per 16-pixel fragment, 16 outputs
+// acc[j][r]; the cout permutation of pack_conv_weights maps them to cout = tile + wn*64 + (j>>1)*32 + g*8 + (j&1)*4 + r:
+// TWO runs of 8 contiguous couts, 32 apart, so that one store instruction writes, for every pixel, 64 contiguous bytes
+// (4 lane groups x 16 B) instead of four 16-byte pieces with gaps.  v[i], i = j*4+r: run h = i>>3, position i&7.
 template <int MF>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn, int fpr,
                                               int lane, int BN, int sub = 1, int sph = 0, int spw = 0) {
     const int g = lane >> 4, pl = lane & 15;
-    const int cout0 = nt * BN + wn * 64 + g * 16;
+    const int cout0 = nt * BN + wn * 64 + g * 8;        // first cout of run 0; run 1 starts at cout0 + 32
     if (a.tail) {
         // CRAFT classifier tail fused behind conv_cls.4 (3x3 32->16 + ReLU): conv_cls.6 (1x1 16->16 + ReLU) as ONE MFMA per
         // fragment, conv_cls.8 (1x1 16->2) as 8 FMAs + a cross-group shuffle reduction; fp32 heat-map [N,h,w,2] out.
-        // Lane group 0 holds the 16 real channels of its pixel; a.tail = {b1[16], w2[32], b2[2]} fp32, a.tail_frag = W1 as
-        // an MFMA A fragment (row = out channel, k = in channel, zero beyond 16).
+        // Run 0 of lane groups 0 and 1 holds channels 8g..8g+7 of the pixel: exactly the B fragment (k = 8g+i) of the next
+        // MFMA.  a.tail = {b1[16], w2[32], b2[2]} fp32, a.tail_frag = W1 as an MFMA A fragment (row = out channel, k = in
+        // channel, zero beyond 16).
         const float* tw = a.tail;
         const bf16x8 w1f = *(const bf16x8*)(a.tail_frag + lane * 8);
-        float cb[16], b1r[4], w2a[4], w2b[4];
+        float cb[8], b1r[4], w2a[4], w2b[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cb[i] = a.bias[i];
+        for (int i = 0; i < 8; ++i) cb[i] = a.bias[(g & 1) * 8 + i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { b1r[r] = tw[4 * g + r]; w2a[r] = tw[16 + 4 * g + r]; w2b[r] = tw[32 + 4 * g + r]; }
         const float b20 = tw[48], b21 = tw[49];
@@ -43,19 +49,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             const int F = wm * MF + f;
             const int fr = F / fpr, fc = F - fr * fpr;
             const int oy = (oy0 + fr) * sub + sph, ox = (ox0 + fc * 16 + pl) * sub + spw;
-            unsigned int pk[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x0 = fmaxf(acc[f][j][0] + cb[j * 4 + 0], 0.f), x1 = fmaxf(acc[f][j][1] + cb[j * 4 + 1], 0.f);
-                const float x2 = fmaxf(acc[f][j][2] + cb[j * 4 + 2], 0.f), x3 = fmaxf(acc[f][j][3] + cb[j * 4 + 3], 0.f);
-                pk[2 * j] = pack_bf16x2(x0, x1);
-                pk[2 * j + 1] = pack_bf16x2(x2, x3);
-            }
             u32x4 bb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned int hi = __shfl(pk[4 + i], pl);          // channels 8..15 of this pixel live in lane group 0
-                bb[i] = g == 0 ? pk[i] : (g == 1 ? hi : 0u);
+            for (int j = 0; j < 2; ++j) {
+                const float x0 = fmaxf(acc[f][j][0] + cb[j * 4 + 0], 0.f), x1 = fmaxf(acc[f][j][1] + cb[j * 4 + 1], 0.f);
+                const float x2 = fmaxf(acc[f][j][2] + cb[j * 4 + 2], 0.f), x3 = fmaxf(acc[f][j][3] + cb[j * 4 + 3], 0.f);
+                bb[2 * j] = g < 2 ? pack_bf16x2(x0, x1) : 0u;
+                bb[2 * j + 1] = g < 2 ? pack_bf16x2(x2, x3) : 0u;
             }
             const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, __builtin_bit_cast(bf16x8, bb), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             float p0 = 0.f, p1 = 0.f;
@@ -71,24 +71,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
         }
         return;
     }
-    if (cout0 >= a.cout_store) return;
+    const bool run0 = cout0 < a.cout_store, run1 = cout0 + 32 < a.cout_store;
+    if (!run0) return;
     float bs[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + j * 4);
-        bs[j * 4 + 0] = b4[0]; bs[j * 4 + 1] = b4[1]; bs[j * 4 + 2] = b4[2]; bs[j * 4 + 3] = b4[3];
-    }
-    auto store16 = [&](void* base, size_t o, const float (&v)[16], bool f32) {
-        if (f32) {
-            float* op = (float*)base + o;
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4*)(op + j * 4) = (f32x4){v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + h * 32 + q * 4);
+            bs[h * 8 + q * 4 + 0] = b4[0]; bs[h * 8 + q * 4 + 1] = b4[1]; bs[h * 8 + q * 4 + 2] = b4[2]; bs[h * 8 + q * 4 + 3] = b4[3];
+        }
+    // Store the 16 pixels of one fragment row: lane (pl, g) owns v[16] of pixel x(pl) = (xb + pl) * sub + spw of the row whose
+    // first element is `row` (elements).  When the wave's 64 couts are all stored (`fullw`) the two 32-byte runs of a pixel
+    // are regrouped across lanes pl <-> pl^8 (two DPP row shifts per dword) so that every store instruction writes WHOLE
+    // 128-byte lines (8 pixels x 128 B) instead of 16 half lines: the CU's store path is priced per line touched
+    // (tools/micro/store_patterns.hip: 64-KB tile burst 5.9k -> 3.9k cycles).
+    const bool fullw = !a.out_f32 && nt * BN + wn * 64 + 64 <= a.cout_store;   // wave-uniform
+    auto pack_runs = [&](const float (&v)[16], u32x4& lo, u32x4& hi) {
+        lo = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        hi = (u32x4){pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+    };
+    auto store_frag = [&](void* base, size_t row, int cs, int xb, int xlim, bool row_ok, const float (&v)[16], bool f32) {
+        if (fullw) {
+            u32x4 lo, hi, dA, dB;
+            pack_runs(v, lo, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // A: lanes pl < 8 keep their run 0, lanes pl >= 8 take run 1 of lane pl-8  -> pixels 0..7 of the fragment
+                dA[i] = (unsigned)__builtin_amdgcn_update_dpp((int)lo[i], (int)hi[i], 0x118 /*row_shr:8*/, 0xF, 0xC, false);
+                // B: lanes pl >= 8 keep their run 1, lanes pl < 8 take run 0 of lane pl+8  -> pixels 8..15
+                dB[i] = (unsigned)__builtin_amdgcn_update_dpp((int)hi[i], (int)lo[i], 0x108 /*row_shl:8*/, 0xF, 0x3, false);
+            }
+            const int co = cout0 + (pl >> 3) * 32;
+            const int xA = (xb + (pl & 7)) * sub + spw, xB = (xb + 8 + (pl & 7)) * sub + spw;
+            uint16_t* op = (uint16_t*)base + row + co;
+            if (row_ok && xA < xlim) *(u32x4*)(op + (size_t)xA * cs) = dA;
+            if (row_ok && xB < xlim) *(u32x4*)(op + (size_t)xB * cs) = dB;
+            return;
+        }
+        const int x = (xb + pl) * sub + spw;
+        if (!(row_ok && x < xlim)) return;
+        if (f32) {
+            float* op = (float*)base + row + (size_t)x * cs + cout0;
+            *(f32x4*)(op) = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            if (run1) {
+                *(f32x4*)(op + 32) = (f32x4){v[8], v[9], v[10], v[11]};
+                *(f32x4*)(op + 36) = (f32x4){v[12], v[13], v[14], v[15]};
+            }
         } else {
-            uint16_t* op = (uint16_t*)base + o;
-            const u32x4 lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            const u32x4 hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+            u32x4 lo, hi;
+            pack_runs(v, lo, hi);
+            uint16_t* op = (uint16_t*)base + row + (size_t)x * cs + cout0;
             *(u32x4*)(op) = lo;
-            *(u32x4*)(op + 8) = hi;
+            if (run1) *(u32x4*)(op + 32) = hi;
         }
     };
     if (a.pool_mode == 0) {
@@ -97,24 +133,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             const int F = wm * MF + f;
             const int fr = F / fpr, fc = F - fr * fpr;
             // sub > 1: the tile lives on one phase (sph, spw) of the dilation lattice (dilated conv run as sub*sub plain convs)
-            const int oy = (oy0 + fr) * sub + sph, ox = (ox0 + fc * 16 + pl) * sub + spw;
-            if (oy < a.OH && ox < a.OW) {
-                float v[16];
+            const int oy = (oy0 + fr) * sub + sph;
+            float v[16];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = acc[f][j][r] + bs[j * 4 + r];
-                        if (a.relu_out) x = fmaxf(x, 0.f);
-                        v[j * 4 + r] = x;
-                    }
-                store16(a.out, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.out_cs + cout0, v, a.out_f32);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[f][j][r] + bs[j * 4 + r];
+                    if (a.relu_out) x = fmaxf(x, 0.f);
+                    v[j * 4 + r] = x;
+                }
+            store_frag(a.out, (size_t)(n * a.OH + oy) * a.OW * a.out_cs, a.out_cs, ox0 + fc * 16, a.OW, oy < a.OH, v, a.out_f32);
         }
         return;
     }
     // ---- fused max-pool (MaxPool2d(2,2) or MaxPool2d((2,1),(2,1))): the two rows of a pooling window are two fragments of
-    // this wave (the launcher only picks tiles with MF % (2*fpr) == 0), the two columns are lanes l and l^1.
+    // this wave (the launcher only picks tiles with MF % (2*fpr) == 0), the two columns are lanes l and l^1.  (sub == 1 here.)
     auto pooled = [&](auto fpr_c) {
         constexpr int FPR = decltype(fpr_c)::value;
         if constexpr (MF % (2 * FPR) == 0) {
@@ -124,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 if ((f / FPR) & 1) continue;                 // odd tile rows are consumed by their even partner
                 const int F = wm * MF + f;
                 const int fr = F / FPR, fc = F - fr * FPR;
-                const int oy = oy0 + fr, ox = ox0 + fc * 16 + pl;
+                const int oy = oy0 + fr, xb = ox0 + fc * 16, ox = xb + pl;
                 float v0[16], v1[16], m[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -138,19 +172,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                         if (a.pool_relu) p = fmaxf(p, 0.f);
                         m[j * 4 + r] = p;
                     }
-                if (a.store_full && ox < a.OW) {
-                    if (oy < a.OH) store16(a.out, ((size_t)(n * a.OH + oy) * a.OW + ox) * a.out_cs + cout0, v0, a.out_f32);
-                    if (oy + 1 < a.OH) store16(a.out, ((size_t)(n * a.OH + oy + 1) * a.OW + ox) * a.out_cs + cout0, v1, a.out_f32);
+                if (a.store_full) {
+                    store_frag(a.out, (size_t)(n * a.OH + oy) * a.OW * a.out_cs, a.out_cs, xb, a.OW, oy < a.OH, v0, a.out_f32);
+                    store_frag(a.out, (size_t)(n * a.OH + oy + 1) * a.OW * a.out_cs, a.out_cs, xb, a.OW, oy + 1 < a.OH, v1, a.out_f32);
                 }
+                const int py = oy >> 1;
+                const size_t prow = (size_t)(n * POH + py) * POW * a.pool_cs;
                 if (a.pool_mode == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], 1));
-                    const int py = oy >> 1, px = ox >> 1;
-                    if (!(pl & 1) && py < POH && px < POW)
-                        store16(a.pool_out, ((size_t)(n * POH + py) * POW + px) * a.pool_cs + cout0, m, false);
+                    const int px = ox >> 1;
+                    u32x4 lo, hi;
+                    pack_runs(m, lo, hi);
+                    uint16_t* op = (uint16_t*)a.pool_out + prow + (size_t)px * a.pool_cs + cout0;
+                    if (fullw) {
+                        // both lanes of a pair hold the pooled pixel: the even one stores run 0, the odd one run 1 -> whole lines
+                        if (py < POH && px < POW) *(u32x4*)(op + (pl & 1) * 32) = (pl & 1) ? hi : lo;
+                    } else if (!(pl & 1) && py < POH && px < POW) {
+                        *(u32x4*)(op) = lo;
+                        if (run1) *(u32x4*)(op + 32) = hi;
+                    }
                 } else {
-                    const int py = oy >> 1;
-                    if (py < POH && ox < POW) store16(a.pool_out, ((size_t)(n * POH + py) * POW + ox) * a.pool_cs + cout0, m, false);
+                    store_frag(a.pool_out, prow, a.pool_cs, xb, POW, py < POH, m, false);
                 }
             }
         }
@@ -465,7 +508,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 //     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
 // vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
 // issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
-template <int WM, int WN, int MF, int NPB, int RING>
+// PERS: persistent walk.  The launch holds 2 workgroups per CU; XCD x owns a contiguous run of logical tiles and its
+// workgroup j takes tiles j, j+W, j+2W, ... of that run.  The LAST chunk of a tile then runs the same static schedule as a
+// middle chunk whose "next chunk" is chunk 0 of the workgroup's NEXT tile (patch DMAs) and whose weight slices wrap into the
+// next tile's first RING-1 slices, so a tile's pipeline fill rides under the previous tile's main loop and its output stores
+// drain under the next one (no s_endpgm drain, no launch of a fresh workgroup per tile).  Stores count in vmcnt and are
+// younger than the prefetched DMAs, so the counted waits of the next tile's first k-steps only ever over-wait.
+template <int WM, int WN, int MF, int NPB, int RING, bool PERS>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -482,53 +531,92 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = bid % a.ntiles_n;
-    bid /= a.ntiles_n;
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    int n = bid / a.tiles_y;
+    const int sub = a.sub;
+    const int nk = a.nchunks * 9;
+    const int fpr = a.TW >> 4;
+
+    // ---- tile walk
+    int tile, tile_end = 0, tile_stride = 0;
+    if constexpr (PERS) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = a.total_tiles >> 3, r = a.total_tiles & 7;
+        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        tile = lo + j;
+        tile_end = lo + q + (x < r ? 1 : 0);
+        tile_stride = gridDim.x >> 3;
+        if (tile >= tile_end) return;
+    } else {
+        tile = xcd_remap(blockIdx.x, gridDim.x);
+    }
     // dilation d (a.sub) with padding d == d*d independent plain 3x3 convs on the phase sub-lattices: image index n' enumerates
     // (n, phase_y, phase_x); tile coordinates are in sub-lattice units
-    const int sub = a.sub;
-    int sph = 0, spw = 0;
-    if (sub > 1) { spw = n % sub; n /= sub; sph = n % sub; n /= sub; }
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int nk = a.nchunks * 9;
-
-    // per-lane source pixel of each 64-pixel block (or -1: padding -> zero page)
-    int src_pix[NPB];
+    struct Geo {
+        int n, nt, oy0, ox0, sph, spw;
+        const unsigned char* wsrc;     // packed weight slices of this tile's cout tile
+    };
+    auto geom = [&](int id, Geo& g) {   // wave-uniform part
+        g.nt = id % a.ntiles_n;
+        id /= a.ntiles_n;
+        const int tx = id % a.tiles_x;
+        id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        int n = id / a.tiles_y;
+        g.sph = 0; g.spw = 0;
+        if (sub > 1) { g.spw = n % sub; n /= sub; g.sph = n % sub; n /= sub; }
+        g.n = n;
+        g.oy0 = ty * a.TH; g.ox0 = tx * a.TW;
+        g.wsrc = (const unsigned char*)a.wpk + (size_t)g.nt * nk * WBUF;
+    };
+    // per-lane source pixel of each 64-pixel patch block of tile g (or -1: padding -> zero page).  ONE array: it describes the
+    // next patch to prefetch -- this tile's until its last chunk starts, the next tile's from then on.
+    int spix[NPB];
+    const int pw_magic = (65536 + a.PW - 1) / a.PW;     // pix / PW == (pix * magic) >> 16 exactly for pix < 448, PW <= 66
+    // lane id recomputed where it is needed outside the main loop (PERS): values derived from it there must not stay live
+    // (and get spilled) across the k-loop -- a scratch reload inside the epilogue waits for every store issued before it
+    auto fresh_lane = [&]() {
+        if constexpr (!PERS) return lane;
+        int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    auto geom_pix = [&](const Geo& g) {
+        const int iy0 = g.oy0 - 1, ix0 = g.ox0 - 1;
+        const int fl = fresh_lane();
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-        const int pix = pb * 64 + lane;
-        const int py = pix / a.PW, px = pix - py * a.PW;
-        const int ly = iy0 + py, lx = ix0 + px;                 // sub-lattice coordinates
-        const int iy = ly * sub + sph, ix = lx * sub + spw;
-        src_pix[pb] = (py < a.PH && ly >= 0 && iy < a.H && lx >= 0 && ix < a.W) ? (n * a.H + iy) * a.W + ix : -1;
-    }
-    auto issue_p = [&](int chunk, auto pb_c) {
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int pix = pb * 64 + fl;
+            const int py = (pix * pw_magic) >> 16, px = pix - py * a.PW;
+            const int ly = iy0 + py, lx = ix0 + px;                 // sub-lattice coordinates
+            const int iy = ly * sub + g.sph, ix = lx * sub + g.spw;
+            spix[pb] = (py < a.PH && ly >= 0 && iy < a.H && lx >= 0 && ix < a.W) ? (g.n * a.H + iy) * a.W + ix : -1;
+        }
+    };
+    auto stamp = [&](int i) {   // diagnostic build of the tile timeline; a.stamps is null in production
+        if constexpr (!PERS) { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + i] = __builtin_amdgcn_s_memtime(); }
+    };
+    stamp(0);
+    Geo cur, nxt;
+    geom(tile, cur);
+    geom_pix(cur);
+
+    auto issue_p = [&](int sp, int chunk, int par, auto pb_c) {
         constexpr int pb = decltype(pb_c)::value;
         const int c = chunk * 32;
         const bool s0 = c < a.C0;
         const uint16_t* src = s0 ? a.in0 : a.in1;
         const int cs = s0 ? a.in0_cs : a.in1_cs;
         const int cb = (s0 ? c : c - a.C0) + wave * 8;
-        const int sp = src_pix[pb];
-        const uint16_t* g = sp >= 0 ? src + (size_t)sp * cs + cb : (const uint16_t*)a.zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(pbuf + (chunk & 1) * patch_bytes + (wave * NP + pb * 64) * 16),
+        const uint16_t* gp = sp >= 0 ? src + (size_t)sp * cs + cb : (const uint16_t*)a.zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(pbuf + par * patch_bytes + (wave * NP + pb * 64) * 16),
                                          16, 0, 0);
     };
-    const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
-    auto issue_w = [&](int ks, int slot) {
+    auto issue_w = [&](const unsigned char* slice, int slot) {
 #pragma unroll
         for (int p0 = 0; p0 < WPIECES; p0 += NT)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slice + (size_t)(p0 + tid) * 16),
                                              (__attribute__((address_space(3))) void*)(wbuf + slot * WBUF + (p0 + wave * 64) * 16), 16, 0, 0);
     };
-    const int fpr = a.TW >> 4;
     int frag_off[MF];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
@@ -538,11 +626,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     }
     const int lane_patch_off = ((lane >> 4) * NP + (lane & 15)) * 16;
     const int lane_w_off = wn * 4 * 1024 + lane * 16;
-    f32x4 acc[MF][4];
-#pragma unroll
-    for (int f = 0; f < MF; ++f)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // patch DMA schedule inside a chunk: PCNT(tap) blocks at tap (first taps take two while NPB > PSLOTS)
     struct Sched {
@@ -564,29 +647,50 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     };
     static_assert(Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
 
-    // prologue: first RING-1 weight slices + the whole first patch
+    // PERS: the tile after `cur` (or `cur` again after the last one: a harmless prefetch that is drained before exit)
+    if constexpr (PERS) {
+        // All workgroups of a persistent launch start together, and two co-resident workgroups that stay in phase run their
+        // epilogues at the same time (MFMA pipe idle) and their main loops at the same time (MFMA pipe contended).  The one
+        // in the odd wave slot therefore starts half a main loop late; the phase difference then persists.
+        if (a.stagger > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1))      // HW_ID.WAVE_ID bit 0
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);      // ~2048 cycles each
+    }
+    // prologue: first RING-1 weight slices + the whole first patch of the first tile
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i)
-        if (i < nk) issue_w(i, i);
-    [&]<int... PB>(std::integer_sequence<int, PB...>) { (issue_p(0, std::integral_constant<int, PB>{}), ...); }(std::make_integer_sequence<int, NPB>{});
+        if (i < nk) issue_w(cur.wsrc + (size_t)i * WBUF, i);
+    [&]<int... PB>(std::integer_sequence<int, PB...>) { (issue_p(spix[PB], 0, 0, std::integral_constant<int, PB>{}), ...); }(std::make_integer_sequence<int, NPB>{});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stamp(1);
 
-    int wslot = 0, ks = 0;
-    auto step = [&](auto tap_c, auto more_c, int c) {
+    int wslot = 0, par = 0;
+    const unsigned char* wp = cur.wsrc + (size_t)(RING - 1) * WBUF;   // next weight slice to issue
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // One k-step.  MORE: a chunk follows (its patch is prefetched, weight slices keep streaming); `cross` (PERS only, runtime,
+    // wave-uniform): that chunk is chunk 0 of the workgroup's next tile.
+    auto step = [&](auto tap_c, auto more_c, int c, bool cross) {
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool MORE = decltype(more_c)::value;
+        if constexpr (PERS && tap == 9 - (RING - 1)) { if (cross) wp = nxt.wsrc; }
         if constexpr (Sched::wcnt(MORE, tap) > 0) {
             int slot = wslot + RING - 1;
             if (slot >= RING) slot -= RING;
-            issue_w(ks + RING - 1, slot);
+            issue_w(wp, slot);
+            wp += WBUF;
         }
         if constexpr (MORE && Sched::pcnt(tap) > 0) {
-            issue_p(c + 1, std::integral_constant<int, Sched::pfirst(tap)>{});
-            if constexpr (Sched::pcnt(tap) > 1) issue_p(c + 1, std::integral_constant<int, Sched::pfirst(tap) + 1>{});
+            constexpr int p0 = Sched::pfirst(tap);
+            const int nc = (PERS && cross) ? 0 : c + 1;
+            issue_p(spix[p0], nc, par ^ 1, std::integral_constant<int, p0>{});
+            if constexpr (Sched::pcnt(tap) > 1) issue_p(spix[p0 + 1], nc, par ^ 1, std::integral_constant<int, p0 + 1>{});
         }
         constexpr int ky = tap / 3, kx = tap % 3;
         const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
-        const unsigned char* pb = pbuf + (c & 1) * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
+        const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
         bf16x8 af[4], bq[MF];
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
@@ -601,17 +705,61 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
-        ++ks;
+        // PERS, chunk 0 of a tile: everything older than the previous tile's output stores landed before they were issued
+        // (vmcnt(0) ahead of the epilogue) and slice ks+1 <= RING-2 is among it, so the first RING-2 k-steps need no vmcnt
+        // wait -- a counted one would also wait for those stores (they sit between the prefetch and this tile's DMAs)
+        if (PERS && tap < RING - 2 && c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
-    auto chunk = [&](auto more_c, int c) {
-        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, 9>{});
+    auto chunk = [&](auto more_c, int c, bool cross) {
+        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c, cross), ...); }(std::make_integer_sequence<int, 9>{});
+        par ^= 1;
     };
-    for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
-    chunk(std::false_type{}, a.nchunks - 1);
-
-    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN, sub, sph, spw);
+    if constexpr (!PERS) {
+        for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c, false);
+        chunk(std::false_type{}, a.nchunks - 1, false);
+        stamp(2);
+        if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+        else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];   // dbg bit 8: timing-only ablation, no epilogue
+        if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+    } else {
+        // ONE copy of the 9-tap body walks every (tile, chunk) of this workgroup; the epilogue sits between two chunks
+        int it = 0;
+        auto pstamp = [&](int i) {   // diagnostic: {main start, main end, epilogue issued, HW_ID | XCC_ID << 32} per (workgroup, tile)
+            if (a.stamps && tid == 0) {
+                unsigned long long v = __builtin_amdgcn_s_memtime();
+                if (i == 3) v = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+                a.stamps[((size_t)blockIdx.x * a.stamp_cap + it) * 4 + i] = v;
+            }
+        };
+        for (int c = 0;;) {
+            const bool last = c + 1 == a.nchunks;
+            if (c == 0) pstamp(0);
+            if (last) {   // from here on the prefetch target is the next tile (or this one again after the last: drained, unused)
+                if (tile + tile_stride < tile_end) geom(tile + tile_stride, nxt);
+                else nxt = cur;
+                geom_pix(nxt);
+            }
+            chunk(std::true_type{}, c, last);
+            if (!last) { ++c; continue; }
+            pstamp(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's prefetch has landed before any output store is issued
+            if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, fresh_lane(), BN, sub, cur.sph, cur.spw);
+            else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];
+            pstamp(2); pstamp(3);
+            ++it;
+            tile += tile_stride;
+            if (tile >= tile_end) break;
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cur = nxt;
+            c = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's (unused) prefetch must land before the LDS is released
+    }
 }
 
 // ================================================================================================ 1x1, LDS-DMA staged
@@ -742,7 +890,7 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
                     const int wn = fr >> 2, nf = fr & 3;
                     for (int l = 0; l < 64; ++l) {
                         const int row = l & 15;
-                        const int cout = nt * BN + wn * 64 + (row >> 2) * 16 + nf * 4 + (row & 3);
+                        const int cout = nt * BN + wn * 64 + (nf >> 1) * 32 + (row >> 2) * 8 + (nf & 1) * 4 + (row & 3);   // see conv_epilogue
                         for (int j = 0; j < 8; ++j) {
                             const int cin = c * 32 + 8 * (l >> 4) + j;
                             float v = 0.f;
@@ -791,9 +939,29 @@ static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 v
     return v;
 }
 
-template <int WM, int WN, int MF, int NPB, int RING>
-static hipError_t launch_dma_one(const ConvArgs& a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING>;
+// BBOCR_CONV_STAMPS=<dir>: diagnostic tile timeline — every 3x3 DMA launch is followed by a sync and dumps its per-workgroup
+// s_memtime stamps to <dir>/stamps_<seq>_<Cin>x<Cout>_<H>x<W>_g<grid>.bin (tools/tile_timeline.py reads them)
+static const char* conv_stamps_dir() {
+    static const char* d = getenv("BBOCR_CONV_STAMPS");
+    return d;
+}
+
+static bool conv_pers() {   // BBOCR_CONV_PERS=0 disables the persistent tile walk of the 3x3 DMA kernel (A/B runs)
+    static const bool v = [] { const char* e = getenv("BBOCR_CONV_PERS"); return !(e && e[0] == '0'); }();
+    return v;
+}
+static int conv_pers_grid() {   // 2 co-resident workgroups per CU, a multiple of the 8 XCDs
+    static const int v = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (2 * cus) / 8 * 8;
+    }();
+    return v;
+}
+
+template <int WM, int WN, int MF, int NPB, int RING, bool PERS>
+static hipError_t launch_dma_k(ConvArgs a, int grid, hipStream_t s) {
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, PERS>;
     const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPB * 64 * 64;
     static bool attr = false;
     if (!attr) {
@@ -801,8 +969,45 @@ static hipError_t launch_dma_one(const ConvArgs& a, int grid, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr = true;
     }
+    {
+        if (const char* dir = conv_stamps_dir()) {
+            static int seq = 0;
+            unsigned long long* dev = nullptr;
+            a.stamp_cap = PERS ? (a.total_tiles + grid - 1) / grid + 1 : 1;
+            const size_t bytes = (size_t)grid * a.stamp_cap * 4 * sizeof(unsigned long long);
+            if (hipMalloc((void**)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipMemsetAsync(dev, 0, bytes, s);
+            a.stamps = dev;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
+            hipError_t e = hipStreamSynchronize(s);
+            if (e == hipSuccess) {
+                unsigned long long* h = (unsigned long long*)malloc(bytes);
+                e = hipMemcpy(h, dev, bytes, hipMemcpyDeviceToHost);
+                char path[512];
+                snprintf(path, sizeof(path), "%s/stamps_%03d_%dx%d_%dx%d_g%d_bn%d_r%d%s.bin", dir, seq++, a.C0 + a.C1, a.ntiles_n * WN * 64, a.H, a.W,
+                         grid, WN * 64, RING, PERS ? "_pers" : "");
+                if (FILE* f = fopen(path, "wb")) { fwrite(h, 1, bytes, f); fclose(f); }
+                free(h);
+            }
+            (void)hipFree(dev);
+            return e;
+        }
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError();
+}
+
+template <int WM, int WN, int MF, int NPB, int RING>
+static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
+    a.total_tiles = grid;
+    static const int stagger_pct = [] { const char* e = getenv("BBOCR_CONV_STAGGER"); return e ? atoi(e) : 100; }();   // A/B knob, % of half a main loop
+    a.stagger = (int)((long long)a.nchunks * 9 * (WN * 256) / 2048 * stagger_pct / 100);   // k-steps x (WN*256 cycles, contended /2) / sleep quantum
+    const int pg = conv_pers_grid();
+    // (the BN=128 instantiations other than NPB 6 / RING 4 spill in their persistent form: plain launch for those)
+    if constexpr (WN == 1 || (NPB == 6 && RING == 4)) {
+        if (conv_pers() && grid >= 2 * pg) return launch_dma_k<WM, WN, MF, NPB, RING, true>(a, pg, s);
+    }
+    return launch_dma_k<WM, WN, MF, NPB, RING, false>(a, grid, s);
 }
 
 template <int WM, int WN, int MF>
