@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -78,6 +79,10 @@ struct Act {   // bf16 NHWC activation
 struct bbocr_ctx {
     bbocr_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
+    std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
+    hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
+    hipEvent_t det_t0 = nullptr, det_t1 = nullptr;   // detector span on `stream` (the host is busy with boxes meanwhile)
     std::mutex mu;
     std::string err;
     float times[8] = {0};
@@ -466,7 +471,8 @@ static DetDims det_dims(int H, int W, int canvas, double mag) {
     return d;
 }
 
-static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bbocr_params& p, float* heat) {
+static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bbocr_params& p, float* heat,
+                        const std::function<void(int, int)>& after_sub = nullptr) {
     if (!c->craft_loaded) fail(BBOCR_ERR_STATE, "detector weights not loaded");
     if (B <= 0 || H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad page batch shape");
     const DetDims d = det_dims(H, W, p.canvas_size, p.mag_ratio);
@@ -494,6 +500,7 @@ static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, c
         }
         c->arena.begin(false);
         craft_forward(c, src, nb, d.th, d.tw, d.H32, d.W32, heat + (size_t)b0 * d.h * d.w * 2);
+        if (after_sub) after_sub(b0, nb);   // everything of this sub-batch is enqueued (nothing has been waited for)
     }
 }
 
@@ -504,7 +511,8 @@ struct HostBoxes {
     std::vector<std::vector<std::array<double, 8>>> freeb;
 };
 
-static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double ratio, const bbocr_params& p, HostBoxes& hb) {
+static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double ratio, const bbocr_params& p, HostBoxes& hb,
+                       hipStream_t st) {
     if (B <= 0 || h <= 0 || w <= 0 || !(ratio > 0)) fail(BBOCR_ERR_ARG, "bad heat-map shape");
     const size_t npx = (size_t)B * h * w;
     const int cap_comps = (int)std::min<size_t>(0x3fffffff, (size_t)B * std::max(1024, h * w / 64));
@@ -515,24 +523,28 @@ static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, dou
     c->ccl_comps.ensure((size_t)cap_comps * sizeof(CclOut));
     c->ccl_rowext.ensure((size_t)cap_rows * 8);
     c->ccl_counters.ensure(16);
-    auto t0 = clk::now();
+    if (!c->ccl_t0) { HIPCHK(hipEventCreate(&c->ccl_t0)); HIPCHK(hipEventCreate(&c->ccl_t1)); }
+    HIPCHK(hipEventRecord(c->ccl_t0, st));
     HIPCHK(launch_ccl(heat, B, h, w, (float)p.low_text, (float)p.link_threshold, (double)p.text_threshold, (int*)c->ccl_label.p,
                       (int*)c->ccl_stat.p, (int*)c->ccl_slot.p, (CclOut*)c->ccl_comps.p, (int*)c->ccl_rowext.p, (int*)c->ccl_counters.p,
-                      cap_comps, cap_rows, c->stream));
+                      cap_comps, cap_rows, st));
+    HIPCHK(hipEventRecord(c->ccl_t1, st));
     int counters[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(counters, c->ccl_counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(counters, c->ccl_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     if (counters[2]) fail(BBOCR_ERR_OVERFLOW, "component buffers too small for this batch");
     std::vector<CclOut> all_comps(counters[0]);
     std::vector<int> all_rows((size_t)counters[1] * 2);
-    if (counters[0]) HIPCHK(hipMemcpyAsync(all_comps.data(), c->ccl_comps.p, all_comps.size() * sizeof(CclOut), hipMemcpyDeviceToHost, c->stream));
-    if (counters[1]) HIPCHK(hipMemcpyAsync(all_rows.data(), c->ccl_rowext.p, all_rows.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (counters[0]) HIPCHK(hipMemcpyAsync(all_comps.data(), c->ccl_comps.p, all_comps.size() * sizeof(CclOut), hipMemcpyDeviceToHost, st));
+    if (counters[1]) HIPCHK(hipMemcpyAsync(all_rows.data(), c->ccl_rowext.p, all_rows.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     std::vector<std::vector<CclOut>> comps(B);
     for (const CclOut& co : all_comps)
         if (co.img >= 0 && co.img < B) comps[co.img].push_back(co);
-    c->times[1] += (float)ms_since(t0);
-    t0 = clk::now();
+    float ccl_ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ccl_ms, c->ccl_t0, c->ccl_t1));
+    c->times[1] += ccl_ms;     // GPU span of the CCL kernels (the host wait before it may include the detector of this sub-batch)
+    auto t0 = clk::now();
     const double ratio_w = 1.0 / ratio, ratio_h = 1.0 / ratio;
     bbocr::GroupParams gp{p.slope_ths, p.ycenter_ths, p.height_ths, p.width_ths, p.add_margin, p.min_size};
     hb.polys.assign(B, {});
@@ -1035,6 +1047,7 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
             return BBOCR_ERR_HIP;
         }
         if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
             delete c;
             return BBOCR_ERR_HIP;
@@ -1051,6 +1064,10 @@ void bbocr_destroy(bbocr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
+    if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
+    if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     free_weights(c);
@@ -1061,6 +1078,7 @@ void bbocr_destroy(bbocr_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -1110,7 +1128,7 @@ int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, doub
         memset(ctx->times, 0, sizeof(ctx->times));
         auto t0 = clk::now();
         HostBoxes hb;
-        boxes_impl(ctx, dev_heat, B, h, w, ratio, pp, hb);
+        boxes_impl(ctx, dev_heat, B, h, w, ratio, pp, hb, ctx->stream);
         *out = export_boxes(hb);
         ctx->times[7] = (float)ms_since(t0);
     });
@@ -1153,11 +1171,39 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
             dev_gray = (const uint8_t*)ctx->gray.p;
         }
         auto t0 = clk::now();
-        detect_impl(ctx, dev_rgb, B, H, W, pp, (float*)ctx->heat.p);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->times[0] = (float)ms_since(t0);
+        // The whole detector is enqueued first (one event per sub-batch, no host wait); box extraction of sub-batch k then
+        // runs on the second stream + host threads while sub-batch k+1 is still in the detector.
+        std::vector<std::pair<int, int>> subs;
+        if (!ctx->det_t0) { HIPCHK(hipEventCreate(&ctx->det_t0)); HIPCHK(hipEventCreate(&ctx->det_t1)); }
+        HIPCHK(hipEventRecord(ctx->det_t0, ctx->stream));
+        detect_impl(ctx, dev_rgb, B, H, W, pp, (float*)ctx->heat.p, [&](int b0, int nb) {
+            if (subs.size() >= ctx->sub_events.size()) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->sub_events.push_back(e);
+            }
+            HIPCHK(hipEventRecord(ctx->sub_events[subs.size()], ctx->stream));
+            subs.push_back({b0, nb});
+        });
+        HIPCHK(hipEventRecord(ctx->det_t1, ctx->stream));
         HostBoxes hb;
-        boxes_impl(ctx, (const float*)ctx->heat.p, B, d.h, d.w, d.ratio, pp, hb);
+        hb.polys.resize(B); hb.hori.resize(B); hb.freeb.resize(B);
+        for (size_t k = 0; k < subs.size(); ++k) {
+            const int b0 = subs[k].first, nb = subs[k].second;
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->sub_events[k], 0));
+            HostBoxes part;
+            boxes_impl(ctx, (const float*)ctx->heat.p + (size_t)b0 * d.h * d.w * 2, nb, d.h, d.w, d.ratio, pp, part, ctx->stream2);
+            for (int i = 0; i < nb; ++i) {
+                hb.polys[b0 + i] = std::move(part.polys[i]);
+                hb.hori[b0 + i] = std::move(part.hori[i]);
+                hb.freeb[b0 + i] = std::move(part.freeb[i]);
+            }
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        float det_ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&det_ms, ctx->det_t0, ctx->det_t1));
+        ctx->times[0] = det_ms;          // GPU span of the detector; box extraction (times[1], times[2]) overlaps it except for the last sub-batch
+        (void)t0;
         std::vector<BoxJob> jobs;
         std::vector<int> off;
         recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);

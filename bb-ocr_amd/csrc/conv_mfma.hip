@@ -508,13 +508,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 //     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
 // vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
 // issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
-// PERS: persistent walk.  The launch holds 2 workgroups per CU; XCD x owns a contiguous run of logical tiles and its
-// workgroup j takes tiles j, j+W, j+2W, ... of that run.  The LAST chunk of a tile then runs the same static schedule as a
-// middle chunk whose "next chunk" is chunk 0 of the workgroup's NEXT tile (patch DMAs) and whose weight slices wrap into the
-// next tile's first RING-1 slices, so a tile's pipeline fill rides under the previous tile's main loop and its output stores
-// drain under the next one (no s_endpgm drain, no launch of a fresh workgroup per tile).  Stores count in vmcnt and are
-// younger than the prefetched DMAs, so the counted waits of the next tile's first k-steps only ever over-wait.
-template <int WM, int WN, int MF, int NPB, int RING, bool PERS>
+template <int WM, int WN, int MF, int NPB, int RING>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -535,19 +529,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int nk = a.nchunks * 9;
     const int fpr = a.TW >> 4;
 
-    // ---- tile walk
-    int tile, tile_end = 0, tile_stride = 0;
-    if constexpr (PERS) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int q = a.total_tiles >> 3, r = a.total_tiles & 7;
-        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-        tile = lo + j;
-        tile_end = lo + q + (x < r ? 1 : 0);
-        tile_stride = gridDim.x >> 3;
-        if (tile >= tile_end) return;
-    } else {
-        tile = xcd_remap(blockIdx.x, gridDim.x);
-    }
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // dilation d (a.sub) with padding d == d*d independent plain 3x3 convs on the phase sub-lattices: image index n' enumerates
     // (n, phase_y, phase_x); tile coordinates are in sub-lattice units
     struct Geo {
@@ -567,24 +549,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         g.oy0 = ty * a.TH; g.ox0 = tx * a.TW;
         g.wsrc = (const unsigned char*)a.wpk + (size_t)g.nt * nk * WBUF;
     };
-    // per-lane source pixel of each 64-pixel patch block of tile g (or -1: padding -> zero page).  ONE array: it describes the
-    // next patch to prefetch -- this tile's until its last chunk starts, the next tile's from then on.
+    // per-lane source pixel of each 64-pixel patch block (or -1: padding -> zero page)
     int spix[NPB];
     const int pw_magic = (65536 + a.PW - 1) / a.PW;     // pix / PW == (pix * magic) >> 16 exactly for pix < 448, PW <= 66
-    // lane id recomputed where it is needed outside the main loop (PERS): values derived from it there must not stay live
-    // (and get spilled) across the k-loop -- a scratch reload inside the epilogue waits for every store issued before it
-    auto fresh_lane = [&]() {
-        if constexpr (!PERS) return lane;
-        int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(l));
-        return l;
-    };
     auto geom_pix = [&](const Geo& g) {
         const int iy0 = g.oy0 - 1, ix0 = g.ox0 - 1;
-        const int fl = fresh_lane();
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
-            const int pix = pb * 64 + fl;
+            const int pix = pb * 64 + lane;
             const int py = (pix * pw_magic) >> 16, px = pix - py * a.PW;
             const int ly = iy0 + py, lx = ix0 + px;                 // sub-lattice coordinates
             const int iy = ly * sub + g.sph, ix = lx * sub + g.spw;
@@ -592,10 +564,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         }
     };
     auto stamp = [&](int i) {   // diagnostic build of the tile timeline; a.stamps is null in production
-        if constexpr (!PERS) { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + i] = __builtin_amdgcn_s_memtime(); }
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    Geo cur, nxt;
+    Geo cur;
     geom(tile, cur);
     geom_pix(cur);
 
@@ -647,14 +619,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     };
     static_assert(Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
 
-    // PERS: the tile after `cur` (or `cur` again after the last one: a harmless prefetch that is drained before exit)
-    if constexpr (PERS) {
-        // All workgroups of a persistent launch start together, and two co-resident workgroups that stay in phase run their
-        // epilogues at the same time (MFMA pipe idle) and their main loops at the same time (MFMA pipe contended).  The one
-        // in the odd wave slot therefore starts half a main loop late; the phase difference then persists.
-        if (a.stagger > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1))      // HW_ID.WAVE_ID bit 0
-            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);      // ~2048 cycles each
-    }
     // prologue: first RING-1 weight slices + the whole first patch of the first tile
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i)
@@ -670,12 +634,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     for (int f = 0; f < MF; ++f)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // One k-step.  MORE: a chunk follows (its patch is prefetched, weight slices keep streaming); `cross` (PERS only, runtime,
-    // wave-uniform): that chunk is chunk 0 of the workgroup's next tile.
-    auto step = [&](auto tap_c, auto more_c, int c, bool cross) {
+    // One k-step.  MORE: a chunk follows (its patch is prefetched, weight slices keep streaming).
+    auto step = [&](auto tap_c, auto more_c, int c) {
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool MORE = decltype(more_c)::value;
-        if constexpr (PERS && tap == 9 - (RING - 1)) { if (cross) wp = nxt.wsrc; }
         if constexpr (Sched::wcnt(MORE, tap) > 0) {
             int slot = wslot + RING - 1;
             if (slot >= RING) slot -= RING;
@@ -684,7 +646,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         }
         if constexpr (MORE && Sched::pcnt(tap) > 0) {
             constexpr int p0 = Sched::pfirst(tap);
-            const int nc = (PERS && cross) ? 0 : c + 1;
+            const int nc = c + 1;
             issue_p(spix[p0], nc, par ^ 1, std::integral_constant<int, p0>{});
             if constexpr (Sched::pcnt(tap) > 1) issue_p(spix[p0 + 1], nc, par ^ 1, std::integral_constant<int, p0 + 1>{});
         }
@@ -705,61 +667,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-        // PERS, chunk 0 of a tile: everything older than the previous tile's output stores landed before they were issued
-        // (vmcnt(0) ahead of the epilogue) and slice ks+1 <= RING-2 is among it, so the first RING-2 k-steps need no vmcnt
-        // wait -- a counted one would also wait for those stores (they sit between the prefetch and this tile's DMAs)
-        if (PERS && tap < RING - 2 && c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
-    auto chunk = [&](auto more_c, int c, bool cross) {
-        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c, cross), ...); }(std::make_integer_sequence<int, 9>{});
+    auto chunk = [&](auto more_c, int c) {
+        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, 9>{});
         par ^= 1;
     };
-    if constexpr (!PERS) {
-        for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c, false);
-        chunk(std::false_type{}, a.nchunks - 1, false);
-        stamp(2);
-        if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
-        else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];   // dbg bit 8: timing-only ablation, no epilogue
-        if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
-    } else {
-        // ONE copy of the 9-tap body walks every (tile, chunk) of this workgroup; the epilogue sits between two chunks
-        int it = 0;
-        auto pstamp = [&](int i) {   // diagnostic: {main start, main end, epilogue issued, HW_ID | XCC_ID << 32} per (workgroup, tile)
-            if (a.stamps && tid == 0) {
-                unsigned long long v = __builtin_amdgcn_s_memtime();
-                if (i == 3) v = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-                a.stamps[((size_t)blockIdx.x * a.stamp_cap + it) * 4 + i] = v;
-            }
-        };
-        for (int c = 0;;) {
-            const bool last = c + 1 == a.nchunks;
-            if (c == 0) pstamp(0);
-            if (last) {   // from here on the prefetch target is the next tile (or this one again after the last: drained, unused)
-                if (tile + tile_stride < tile_end) geom(tile + tile_stride, nxt);
-                else nxt = cur;
-                geom_pix(nxt);
-            }
-            chunk(std::true_type{}, c, last);
-            if (!last) { ++c; continue; }
-            pstamp(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's prefetch has landed before any output store is issued
-            if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, fresh_lane(), BN, sub, cur.sph, cur.spw);
-            else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];
-            pstamp(2); pstamp(3);
-            ++it;
-            tile += tile_stride;
-            if (tile >= tile_end) break;
-#pragma unroll
-            for (int f = 0; f < MF; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            cur = nxt;
-            c = 0;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's (unused) prefetch must land before the LDS is released
-    }
+    for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
+    chunk(std::false_type{}, a.nchunks - 1);
+    stamp(2);
+    if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+    else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];   // dbg bit 8: timing-only ablation, no epilogue
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
 }
 
 // ================================================================================================ 1x1, LDS-DMA staged
@@ -946,22 +866,9 @@ static const char* conv_stamps_dir() {
     return d;
 }
 
-static bool conv_pers() {   // BBOCR_CONV_PERS=0 disables the persistent tile walk of the 3x3 DMA kernel (A/B runs)
-    static const bool v = [] { const char* e = getenv("BBOCR_CONV_PERS"); return !(e && e[0] == '0'); }();
-    return v;
-}
-static int conv_pers_grid() {   // 2 co-resident workgroups per CU, a multiple of the 8 XCDs
-    static const int v = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return (2 * cus) / 8 * 8;
-    }();
-    return v;
-}
-
-template <int WM, int WN, int MF, int NPB, int RING, bool PERS>
-static hipError_t launch_dma_k(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, PERS>;
+template <int WM, int WN, int MF, int NPB, int RING>
+static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING>;
     const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPB * 64 * 64;
     static bool attr = false;
     if (!attr) {
@@ -969,45 +876,29 @@ static hipError_t launch_dma_k(ConvArgs a, int grid, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    {
-        if (const char* dir = conv_stamps_dir()) {
-            static int seq = 0;
-            unsigned long long* dev = nullptr;
-            a.stamp_cap = PERS ? (a.total_tiles + grid - 1) / grid + 1 : 1;
-            const size_t bytes = (size_t)grid * a.stamp_cap * 4 * sizeof(unsigned long long);
-            if (hipMalloc((void**)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
-            (void)hipMemsetAsync(dev, 0, bytes, s);
-            a.stamps = dev;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
-            hipError_t e = hipStreamSynchronize(s);
-            if (e == hipSuccess) {
-                unsigned long long* h = (unsigned long long*)malloc(bytes);
-                e = hipMemcpy(h, dev, bytes, hipMemcpyDeviceToHost);
-                char path[512];
-                snprintf(path, sizeof(path), "%s/stamps_%03d_%dx%d_%dx%d_g%d_bn%d_r%d%s.bin", dir, seq++, a.C0 + a.C1, a.ntiles_n * WN * 64, a.H, a.W,
-                         grid, WN * 64, RING, PERS ? "_pers" : "");
-                if (FILE* f = fopen(path, "wb")) { fwrite(h, 1, bytes, f); fclose(f); }
-                free(h);
-            }
-            (void)hipFree(dev);
-            return e;
+    if (const char* dir = conv_stamps_dir()) {
+        static int seq = 0;
+        unsigned long long* dev = nullptr;
+        const size_t bytes = (size_t)grid * 4 * sizeof(unsigned long long);
+        if (hipMalloc((void**)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(dev, 0, bytes, s);
+        a.stamps = dev;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            unsigned long long* h = (unsigned long long*)malloc(bytes);
+            e = hipMemcpy(h, dev, bytes, hipMemcpyDeviceToHost);
+            char path[512];
+            snprintf(path, sizeof(path), "%s/stamps_%03d_%dx%d_%dx%d_g%d_bn%d_r%d.bin", dir, seq++, a.C0 + a.C1, a.ntiles_n * WN * 64, a.H, a.W, grid,
+                     WN * 64, RING);
+            if (FILE* f = fopen(path, "wb")) { fwrite(h, 1, bytes, f); fclose(f); }
+            free(h);
         }
+        (void)hipFree(dev);
+        return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError();
-}
-
-template <int WM, int WN, int MF, int NPB, int RING>
-static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    a.total_tiles = grid;
-    static const int stagger_pct = [] { const char* e = getenv("BBOCR_CONV_STAGGER"); return e ? atoi(e) : 100; }();   // A/B knob, % of half a main loop
-    a.stagger = (int)((long long)a.nchunks * 9 * (WN * 256) / 2048 * stagger_pct / 100);   // k-steps x (WN*256 cycles, contended /2) / sleep quantum
-    const int pg = conv_pers_grid();
-    // (the BN=128 instantiations other than NPB 6 / RING 4 spill in their persistent form: plain launch for those)
-    if constexpr (WN == 1 || (NPB == 6 && RING == 4)) {
-        if (conv_pers() && grid >= 2 * pg) return launch_dma_k<WM, WN, MF, NPB, RING, true>(a, pg, s);
-    }
-    return launch_dma_k<WM, WN, MF, NPB, RING, false>(a, grid, s);
 }
 
 template <int WM, int WN, int MF>

@@ -28,9 +28,6 @@ struct ConvArgs {
     const uint16_t* tail_frag;
     int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
-    int total_tiles;       // persistent 3x3 DMA variant: logical tiles of the launch (set by launch_conv)
-    int stagger;           // persistent variant: start delay (s_sleep 32 quanta) of the workgroup in the odd wave slot
-    int stamp_cap;         // diagnostic: stamp records per workgroup
     unsigned long long* stamps;   // diagnostic (BBOCR_CONV_STAMPS): per workgroup {t_start, t_prologue, t_mainloop, t_end} s_memtime; null in production
 };
 

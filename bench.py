@@ -149,7 +149,7 @@ def main():
     }
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     result["roofline"] = {
-        "kernel": "conv_mfma_kernel (detector launches: conv1_2..conv_cls.4, 25 per sub-batch)",
+        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel (detector launches conv1_2..conv_cls.4, 24 per sub-batch)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
         "traffic": None,
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
