@@ -508,13 +508,16 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 //     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
 // vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
 // issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
-template <int WM, int WN, int MF, int NPB, int RING>
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
     constexpr int WBUF = BN * 64, WPIECES = WBUF / 16, WPT = WPIECES / NT;
     static_assert(WPIECES % NT == 0 && (RING == 3 || RING == 4), "uniform DMA issue");
-    constexpr int NP = NPB * 64, PSLOTS = 10 - RING;      // taps 0 .. 9-RING may issue patch DMAs
+    // NPS: pixels per channel group in the LDS patch image; NPS < NPB*64 (exactly PH*PW) trims the patch to what the tile needs,
+    // the last 64-pixel DMA block then runs with the lanes beyond NPS masked off
+    constexpr int NP = NPS, PSLOTS = 10 - RING;           // taps 0 .. 9-RING may issue patch DMAs
+    static_assert(NPS <= NPB * 64 && NPS > (NPB - 1) * 64 && NPS % 4 == 0, "patch size");
     static_assert(NPB <= 2 * PSLOTS, "patch does not fit the DMA schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wbuf = smem;                    // [RING][WBUF]
@@ -579,9 +582,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         const int cs = s0 ? a.in0_cs : a.in1_cs;
         const int cb = (s0 ? c : c - a.C0) + wave * 8;
         const uint16_t* gp = sp >= 0 ? src + (size_t)sp * cs + cb : (const uint16_t*)a.zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                         (__attribute__((address_space(3))) void*)(pbuf + par * patch_bytes + (wave * NP + pb * 64) * 16),
-                                         16, 0, 0);
+        if ((pb + 1) * 64 <= NPS || pb * 64 + lane < NPS)     // (still one vmcnt event per wave: every wave has lanes below NPS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(pbuf + par * patch_bytes + (wave * NP + pb * 64) * 16),
+                                             16, 0, 0);
     };
     auto issue_w = [&](const unsigned char* slice, int slot) {
 #pragma unroll
@@ -866,10 +870,10 @@ static const char* conv_stamps_dir() {
     return d;
 }
 
-template <int WM, int WN, int MF, int NPB, int RING>
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING>;
-    const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPB * 64 * 64;
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS>;
+    const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -906,6 +910,13 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
     const size_t wb = (size_t)WN * 64 * 64, pb = (size_t)2 * npb * 64 * 64;
     static const int ring_cap = [] { const char* e = getenv("BBOCR_DMA_RING"); return e ? atoi(e) : 4; }();
     const bool r4 = ring_cap >= 4 && 4 * wb + pb <= 80 * 1024;      // deepest ring that still lets two workgroups share a CU
+    if constexpr (WN == 1) {
+        // BN = 64: k-steps are short (16 MFMAs per wave), what pays is a THIRD co-resident workgroup: 16x16 tiles with the patch
+        // trimmed to its 18 x 18 = 324 pixels and a 3-deep weight ring are 53,760 B of LDS (3 x 53,760 <= 160 KB)
+        static const bool three = [] { const char* e = getenv("BBOCR_CONV_3WG"); return !(e && e[0] == '0'); }();
+        if (three && npb == 6 && a.PH * a.PW == 324) return launch_dma_one<WM, WN, MF, 6, 3, 324>(a, grid, s);
+        if (npb == 6) return launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
+    }
     if (npb == 6) return r4 ? launch_dma_one<WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);
     if (npb == 7) return launch_dma_one<WM, WN, MF, 7, 3>(a, grid, s);
     return hipErrorInvalidValue;
@@ -917,7 +928,8 @@ static bool conv_small_wg() {   // BBOCR_CONV_WG=512 selects the original one-wo
 }
 
 int conv_plan_bn(int Cout) {
-    if (conv_small_wg()) return Cout > 64 ? 128 : 64;
+    static const int bn64_upto = [] { const char* e = getenv("BBOCR_BN64_UPTO"); return e ? atoi(e) : 64; }();   // A/B knob
+    if (conv_small_wg()) return Cout > bn64_upto ? 128 : 64;
     return Cout >= 256 ? 256 : (Cout > 64 ? 128 : 64);
 }
 
