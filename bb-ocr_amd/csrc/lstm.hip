@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
 
@@ -180,21 +181,30 @@ __global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict
 }
 
 // ================================================================================================ 8-wave variant
-// Same recurrence, eight waves per workgroup (two per SIMD): wave w owns hidden units [32w, 32w+32) = two 16-unit groups,
-// 64 MFMAs per step.  Two waves share a SIMD, so one wave's lane-local gate math (transcendental-bound) overlaps the
-// other's MFMA stream; per-step critical path ~ the MFMA floor (128 MFMAs per SIMD) instead of MFMA + VALU in series.
-// Weight residency per wave (64 fragments): LSTM8_NR in registers, LSTM8_NL in LDS, the rest streamed from L2.
-// Packed layout [dir][wave 8][group 2][kk 8][gate 4][lane 64][8]; input-projection channels permuted so that a lane's 8
-// gate pre-activations of one sequence are 16 contiguous bytes (lstm8_xproj_channel).
+// Same recurrence, eight waves per workgroup (two per SIMD): wave w owns hidden units [32w, 32w+32) = two 16-unit groups
+// x four gates = 64 weight fragments (1 KiB each), one MFMA per fragment and step.  A step is [64 MFMAs][gate math][barrier];
+// what bounds it is latency, so every operand of the MFMA stream is in a register BEFORE its MFMA is due:
+//   visit order v = kk*8 + group*4 + gate (kk = 32-wide slice of h), fragment v lives
+//     v in [10,38)            28 fragments  in registers for all T steps,
+//     v in [46,64)            18 fragments  in LDS (read LSTM8_LD MFMAs ahead into a small register ring),
+//     v in [0,10) u [38,46)   18 fragments  re-streamed from L2 every step through a 10-fragment register buffer: the first
+//                                           ten are loaded during the PREVIOUS step's gate math (the buffer is idle then), the
+//                                           other eight as the first ten are consumed -- 28 register MFMAs later they are due.
+//   h fragments are read one kk ahead (2 x 4 registers instead of all eight), x_t is loaded at the top of its own step.
+// Packed layout [dir][wave 8][v 64][lane 64][8]; input-projection channels permuted so that a lane's 8 gate
+// pre-activations of one sequence are 16 contiguous bytes (lstm8_xproj_channel).
+#define LSTM8_S0 10     // streamed fragments held at the top of a step
 #define LSTM8_NR 28
+#define LSTM8_S1 8      // streamed fragments fetched while the first ones are consumed
 #define LSTM8_NL 18
+#define LSTM8_LD 8      // LDS read-ahead (fragments); the ring reuses the registers of the (by then consumed) streamed buffer
 void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
     size_t o = 0;
     for (int d = 0; d < 2; ++d) {
         const float* W = d ? whh_bwd : whh_fwd;
         for (int w = 0; w < 8; ++w)
-            for (int a = 0; a < 2; ++a)
-                for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < 8; ++kk)
+                for (int a = 0; a < 2; ++a)
                     for (int gate = 0; gate < 4; ++gate)
                         for (int l = 0; l < 64; ++l) {
                             const int unit = w * 32 + a * 16 + (l & 15);
@@ -209,6 +219,8 @@ int lstm8_xproj_channel(int dir, int gate, int unit) {
 
 __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
                                                        uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
+    static_assert(LSTM8_S0 + LSTM8_NR + LSTM8_S1 + LSTM8_NL == 64 && LSTM8_S1 <= LSTM8_S0, "fragment classes");
+    constexpr int R0 = LSTM8_S0, S1 = LSTM8_S0 + LSTM8_NR, L0 = S1 + LSTM8_S1;   // first v of the register / late-streamed / LDS class
     extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
     unsigned char (*hbuf)[32 * 16 * 16] = (unsigned char (*)[32 * 16 * 16])lstm_smem;   // [2][kgroup 32][seq 16] x 16 B
     unsigned char* const wlds = lstm_smem + 2 * 32 * 16 * 16;                             // [wave 8][LSTM8_NL][lane 64] x 16 B
@@ -224,55 +236,66 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
-    const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane;
+    typedef const __attribute__((address_space(1))) bf16x8* gfrag_ptr;     // global_load (vmcnt only), never flat_load
+    const gfrag_ptr wv0 = (gfrag_ptr)((const bf16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane);
     bf16x8 wreg[LSTM8_NR];
 #pragma unroll
-    for (int i = 0; i < LSTM8_NR; ++i) wreg[i] = wv0[(size_t)i * 64];
+    for (int i = 0; i < LSTM8_NR; ++i) wreg[i] = wv0[(size_t)(R0 + i) * 64];
     bf16x8* const wl = (bf16x8*)(wlds + (size_t)wave * LSTM8_NL * 1024) + lane;
 #pragma unroll 2
-    for (int i = 0; i < LSTM8_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(LSTM8_NR + i) * 64];
+    for (int i = 0; i < LSTM8_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(L0 + i) * 64];
     const int xch = dir * 1024 + (wave * 16 + u) * 8;
     const int wb_seq = tid >> 5, wb_kg = tid & 31;   // h write-back: 16 B per thread
-    auto load_x = [&](int step, u32x4 (&xq)[4]) {
-        const int t = dir ? (T - 1 - step) : step;
+    // rows beyond n only feed their own (never stored) outputs: clamp their address instead of branching around the load
+    size_t xrow[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = g * 4 + r;
-            if (s < n && step < T) xq[r] = *(const u32x4*)(xproj + ((size_t)row0 + (size_t)s * T + t) * 2048 + xch);
-            else xq[r] = (u32x4){0u, 0u, 0u, 0u};
-        }
+    for (int r = 0; r < 4; ++r) xrow[r] = ((size_t)row0 + (size_t)(g * 4 + r < n ? g * 4 + r : n - 1) * T) * 2048 + xch;
+    bf16x8 sb[LSTM8_S0];
+    auto stream_head = [&]() {        // fragments v = 0 .. S0-1 of the NEXT step
+        gfrag_ptr wv = wv0;
+        asm volatile("" : "+v"(wv));  // keep these loads inside the time loop (they would otherwise be hoisted and spilled)
+#pragma unroll
+        for (int i = 0; i < LSTM8_S0; ++i) sb[i] = wv[(size_t)i * 64];
     };
-    u32x4 xq[4], xn[4];
-    load_x(0, xq);
+    stream_head();
     __syncthreads();
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        load_x(step + 1, xn);
-        const unsigned char* hb = hbuf[cur];
-        unsigned char* hn = hbuf[cur ^ 1];
-        const bf16x8* wv = wv0;
-        asm volatile("" : "+v"(wv));     // keep the streamed fragment loads inside the time loop
-        bf16x8 af[8];
+        u32x4 xq[4];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) af[kk] = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
+        for (int r = 0; r < 4; ++r) xq[r] = *(const u32x4*)(xproj + xrow[r] + (size_t)t * 2048);
+        const unsigned char* hb = hbuf[cur] + (g * 16 + u) * 16;
+        unsigned char* hn = hbuf[cur ^ 1];
+        gfrag_ptr wv = wv0;
+        asm volatile("" : "+v"(wv));
         f32x4 acc[2][4];
-        auto mfma_group = [&](auto a_c) {
-            constexpr int a = decltype(a_c)::value;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int fi = a * 32 + kk * 4 + q;
-                    bf16x8 bfr;
-                    if (fi < LSTM8_NR) bfr = wreg[fi < LSTM8_NR ? fi : 0];
-                    else if (fi < LSTM8_NR + LSTM8_NL) bfr = wl[(size_t)(fi - LSTM8_NR) * 64];
-                    else bfr = wv[(size_t)fi * 64];
-                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[a][q], 0, 0, 0);
-                }
+        bf16x8 af[2], lb[LSTM8_LD];
+        af[0] = *(const bf16x8*)(hb);
+        auto visit = [&](auto v_c) {
+            constexpr int v = decltype(v_c)::value;
+            constexpr int kk = v >> 3, a = (v >> 2) & 1, q = v & 3;
+            if constexpr ((v & 7) == 0 && kk + 1 < 8) af[(kk + 1) & 1] = *(const bf16x8*)(hb + (kk + 1) * 4 * 256);   // h slice kk+1, one slice ahead
+            bf16x8 w;
+            if constexpr (v < R0) w = sb[v];
+            else if constexpr (v < S1) w = wreg[v - R0];
+            else if constexpr (v < L0) w = sb[v - S1];
+            else w = lb[(v - L0) % LSTM8_LD];
+            acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk & 1], w, acc[a][q], 0, 0, 0);
+            if constexpr (v < LSTM8_S1) sb[v] = wv[(size_t)(S1 + v) * 64];      // the buffer slot is free again: late fragment v
+            // LDS read-ahead: fragment v+LD goes into the ring slot fragment v just left (the first LD reads fill the empty ring)
+            if constexpr (v + LSTM8_LD >= L0 && v + LSTM8_LD < 64) lb[(v + LSTM8_LD - L0) % LSTM8_LD] = wl[(size_t)(v + LSTM8_LD - L0) * 64];
+            // hipcc sinks loads towards their use to save registers, which would put the L2 latency back in front of the MFMA:
+            // nothing may be scheduled across the end of the refill block
+            if constexpr (v == LSTM8_S1 - 1 || v >= L0 - LSTM8_LD - 1) __builtin_amdgcn_sched_barrier(0);   // (and the LDS read-ahead distance)
         };
+        [&]<int... V>(std::integer_sequence<int, V...>) { (visit(std::integral_constant<int, V>{}), ...); }(std::make_integer_sequence<int, 64>{});
+        stream_head();               // next step's first fragments travel while the gate math runs
+        __builtin_amdgcn_sched_barrier(0);
         auto gate_group = [&](auto a_c) {
             constexpr int a = decltype(a_c)::value;
             const int unit = wave * 32 + a * 16 + u;
@@ -289,8 +312,6 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
                 *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
             }
         };
-        mfma_group(std::integral_constant<int, 0>{});
-        mfma_group(std::integral_constant<int, 1>{});
         gate_group(std::integral_constant<int, 0>{});
         gate_group(std::integral_constant<int, 1>{});
         __syncthreads();
@@ -298,8 +319,6 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
             const u32x4 h0 = *(const u32x4*)(hn + (wb_kg * 16 + wb_seq) * 16);
             *(u32x4*)(out + ((size_t)row0 + (size_t)wb_seq * T + t) * 512 + dir * 256 + wb_kg * 8) = h0;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xq[r] = xn[r];
         cur ^= 1;
     }
 }
