@@ -79,6 +79,9 @@ struct Act {   // bf16 NHWC activation
 struct bbocr_ctx {
     bbocr_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t cur = nullptr;                // stream the layer helpers launch on (stream, or a recogniser side stream)
+    hipStream_t rstream[4] = {nullptr, nullptr, nullptr, nullptr};   // recogniser conv stacks of different width buckets run side by side
+    hipEvent_t rjoin[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
     std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
     hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
@@ -320,7 +323,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
 static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
     a.zero = c->zero_page;
     if (!c->profiling) {
-        HIPCHK(launch_conv(p, a, c->stream));
+        HIPCHK(launch_conv(p, a, c->cur));
         return;
     }
     auto get_event = [&]() {
@@ -335,9 +338,9 @@ static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
     const int OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     r.flops = 2.0 * a.N * OH * OW * (double)p.Cout * p.Cin * p.KH * p.KW;   // algorithmic (unpadded) work
     r.group = c->prof_group;
-    HIPCHK(hipEventRecord(r.e0, c->stream));
-    HIPCHK(launch_conv(p, a, c->stream));
-    HIPCHK(hipEventRecord(r.e1, c->stream));
+    HIPCHK(hipEventRecord(r.e0, c->cur));
+    HIPCHK(launch_conv(p, a, c->cur));
+    HIPCHK(hipEventRecord(r.e1, c->cur));
     c->prof_recs.push_back(r);
 }
 
@@ -398,13 +401,13 @@ static Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool re
 static Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, int ph, int pw, bool relu_in) {
     const int OH = (a.H + 2 * ph - kh) / sh + 1, OW = (a.W + 2 * pw - kw) / sw + 1;
     Act o{c->arena.alloc<uint16_t>((size_t)a.N * OH * OW * a.C), a.N, OH, OW, a.C};
-    if (!c->arena.dry) HIPCHK(launch_maxpool(a.p, o.p, a.N, a.H, a.W, a.C, kh, kw, sh, sw, ph, pw, relu_in, c->stream));
+    if (!c->arena.dry) HIPCHK(launch_maxpool(a.p, o.p, a.N, a.H, a.W, a.C, kh, kw, sh, sw, ph, pw, relu_in, c->cur));
     return o;
 }
 
 static Act up_act(bbocr_ctx* c, const Act& a) {
     Act o{c->arena.alloc<uint16_t>((size_t)a.N * 4 * a.H * a.W * a.C), a.N, 2 * a.H, 2 * a.W, a.C};
-    if (!c->arena.dry) HIPCHK(launch_upsample2x(a.p, o.p, a.N, a.H, a.W, a.C, c->stream));
+    if (!c->arena.dry) HIPCHK(launch_upsample2x(a.p, o.p, a.N, a.H, a.W, a.C, c->cur));
     return o;
 }
 
@@ -414,7 +417,7 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     Arena& ar = c->arena;
     c->prof_group = 0;
     Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
-    if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->stream));
+    if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->cur));
     Act p1 = conv_pool_act(c, c->conv1_2, a1, false, true, 64, 1, false, nullptr);          // conv1_2+BN+ReLU+pool fused
     Act a3 = conv_act(c, c->conv2_1, p1, false, nullptr, false, true, 128);
     Act s1;                                                                        // slice1 ends on BatchNorm (skip tensor),
@@ -704,14 +707,14 @@ static void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, 
     c->prof_group = 1;
     const int T = imgW / 4 - 1;
     Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32), n, 32, imgW / 2, 32};
-    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->stream));
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->cur));
     Act q1 = conv_pool_act(c, c->r1, c0, false, true, 64, 1, false, nullptr);
     Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
     Act q2 = conv_pool_act(c, c->r3, c2, false, true, 128, 2, false, nullptr);
     Act c4 = conv_act(c, c->r4, q2, false, nullptr, false, true, 256);
     Act q3 = conv_pool_act(c, c->r5, c4, false, true, 256, 2, false, nullptr);
     Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [n,3,T,256]
-    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->stream));
+    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->cur));
 }
 
 // Sequence half of the recogniser over the POOLED time steps of every bucket (rows = sum n_i*T_i, padded to x256):
@@ -800,19 +803,30 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
         t0 = clk::now();
         std::vector<int> tiles, seqs;   // int4 / int2 tables
         std::vector<int> seq_k;         // sel position of each pooled sequence
-        for (size_t ci = g0; ci < g1; ++ci) {
-            const RecChunk& ch = chunks[ci];
-            uint16_t* crops = nullptr;
-            for (int pass = 0; pass < 2; ++pass) {
-                c->arena.begin(pass == 0);
-                crops = c->arena.alloc<uint16_t>((size_t)ch.n * 64 * ch.imgW);
+        // Conv stacks of the group's chunks: every chunk has its own activations (one arena sized by a dry pass over all of
+        // them) and the chunks are dealt round-robin over a few side streams, so the many small launches of narrow buckets
+        // overlap instead of each paying its own ramp-up and tail on an otherwise idle GPU.
+        for (int pass = 0; pass < 2; ++pass) {
+            c->arena.begin(pass == 0);
+            for (size_t ci = g0; ci < g1; ++ci) {
+                const RecChunk& ch = chunks[ci];
+                c->cur = c->rstream[(ci - g0) % 4];
+                uint16_t* crops = c->arena.alloc<uint16_t>((size_t)ch.n * 64 * ch.imgW);
                 if (pass == 1)
                     HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, ch.first, ch.n, ch.imgW, any_warp, any_tall,
                                         (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
-                                        (const uint8_t*)c->crop_luts.p, crops, 2, c->stream));
+                                        (const uint8_t*)c->crop_luts.p, crops, 2, c->cur));
                 crnn_features(c, crops, ch.n, ch.imgW, (uint16_t*)c->seq_v.p + ch.row0 * 256);
-                if (pass == 0) c->arena.buf.ensure(c->arena.off);
             }
+            c->cur = c->stream;
+            if (pass == 0) c->arena.buf.ensure(c->arena.off);
+        }
+        for (int k = 0; k < 4; ++k) {
+            HIPCHK(hipEventRecord(c->rjoin[k], c->rstream[k]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->rjoin[k], 0));
+        }
+        for (size_t ci = g0; ci < g1; ++ci) {
+            const RecChunk& ch = chunks[ci];
             for (int s0 = 0; s0 < ch.n; s0 += 16) {
                 tiles.push_back((int)(ch.row0 + (size_t)s0 * ch.T));
                 tiles.push_back(std::min(16, ch.n - s0));
@@ -1006,6 +1020,7 @@ template <typename F> static int guarded(bbocr_ctx* ctx, F&& f) {
     try {
         hipError_t e = hipSetDevice(ctx->cfg.device);
         if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        ctx->cur = ctx->stream;
         f();
         return BBOCR_OK;
     } catch (const StatusError& se) {
@@ -1048,6 +1063,14 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
         }
         if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->rstream[0], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->rstream[1], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->rstream[2], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->rstream[3], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->rjoin[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->rjoin[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->rjoin[2], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->rjoin[3], hipEventDisableTiming) != hipSuccess ||
             hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
             delete c;
             return BBOCR_ERR_HIP;
@@ -1056,6 +1079,7 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
         delete c;
         return BBOCR_ERR_INTERNAL;
     }
+    c->cur = c->stream;
     *out = c;
     return BBOCR_OK;
 }
@@ -1065,6 +1089,10 @@ void bbocr_destroy(bbocr_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (int k = 0; k < 4; ++k) {
+        if (c->rstream[k]) { (void)hipStreamSynchronize(c->rstream[k]); (void)hipStreamDestroy(c->rstream[k]); }
+        if (c->rjoin[k]) (void)hipEventDestroy(c->rjoin[k]);
+    }
     for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
     if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
     if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }

@@ -11,7 +11,7 @@ starts = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('gray_ker
 a = starts[-1]
 step = rows[a:]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
-ccl = next(i for i, r in enumerate(step) if r['Kernel_Name'].startswith('ccl_init'))
+ccl = max(i for i, r in enumerate(step) if r['Kernel_Name'].startswith('ccl_rowext')) + 1   # end of the last box extraction
 def part(rs, label):
     busy = collections.OrderedDict(); cnt = collections.Counter()
     gaps = 0; prev_end = None; biggaps = []
@@ -21,7 +21,7 @@ def part(rs, label):
         busy[n] = busy.get(n, 0) + (e - s); cnt[n] += 1
         if prev_end is not None and s > prev_end:
             gaps += s - prev_end
-            if s - prev_end > 100000: biggaps.append(((s - prev_end) / 1e3, n))
+            if s - prev_end > 60000: biggaps.append(((s - prev_end) / 1e3, n))
         prev_end = max(prev_end or 0, e)
     span = int(rs[-1]['End_Timestamp']) - int(rs[0]['Start_Timestamp'])
     print(f"== {label}: span {span/1e6:.2f} ms, idle between kernels {gaps/1e6:.2f} ms, {len(rs)} launches")
@@ -29,5 +29,5 @@ def part(rs, label):
         print(f"   {n[:60]:60s} {cnt[n]:5d} calls {b/1e6:8.3f} ms")
     print("   gaps > 100 us before:", ", ".join(f"{g:.0f}us->{n[:24]}" for g, n in biggaps[:12]))
 part(step[:ccl], "detector")
-part(step[ccl:], "boxes + recogniser")
+part(step[ccl:], "recogniser (after the last box extraction)")
 print(f"step span {(t1 - t0)/1e6:.2f} ms")
