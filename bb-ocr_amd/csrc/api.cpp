@@ -104,7 +104,10 @@ struct bbocr_ctx {
     uint16_t* c11_w = nullptr;
     float* c11_b = nullptr;
     ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
-    ConvPlan up1a, up1b, up2a, up2b, up3a, up3b, up4a, up4b, cls0, cls2, cls4;
+    ConvPlan up1a, up1b, up2b, up3b, up4b, cls0, cls2, cls4;
+    // U-net 1x1 layers over cat[up(y), skip], split by linearity: upNy = the columns of y (no bias, run at y's resolution),
+    // upNs = the columns of the skip tensor (+ bias), whose epilogue adds the 2x bilinear up-sampling of upNy's output
+    ConvPlan up2y, up2s, up3y, up3s, up4y, up4s;
     float* cls_tail = nullptr;   // b1[16] w2[32] b2[2]
     uint16_t* cls_tail_frag = nullptr;   // conv_cls.6 weight as an MFMA A fragment
     // ---- recogniser
@@ -197,6 +200,22 @@ static void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, 
     p.d_b = upload(c, bp);
 }
 
+// 1x1 conv over a channel concat [y (Cy) | skip (Cs)], BN folded, split into the two column blocks
+static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, ConvPlan& ps, const std::string& conv, const std::string& bn, int Cy,
+                           int Cs, int Cout) {
+    std::vector<float> w, b;
+    fold_conv(tm, conv, bn, Cout, Cy + Cs, 1, w, b);
+    std::vector<float> wy((size_t)Cout * Cy), ws((size_t)Cout * Cs), zero(Cout, 0.f);
+    for (int o = 0; o < Cout; ++o) {
+        std::copy(w.begin() + (size_t)o * (Cy + Cs), w.begin() + (size_t)o * (Cy + Cs) + Cy, wy.begin() + (size_t)o * Cy);
+        std::copy(w.begin() + (size_t)o * (Cy + Cs) + Cy, w.begin() + (size_t)(o + 1) * (Cy + Cs), ws.begin() + (size_t)o * Cs);
+    }
+    py = make_plan(Cy, Cout, 1, 1, 0, 1);
+    upload_plan(c, py, wy, zero);
+    ps = make_plan(Cs, Cout, 1, 1, 0, 1);
+    upload_plan(c, ps, ws, b);
+}
+
 static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std::string& conv, const std::string& bn, int Cin, int Cout,
                        int K, int pad, int dil) {
     p = make_plan(Cin, Cout, K, K, pad, dil);
@@ -235,11 +254,11 @@ static void load_craft(bbocr_ctx* c, const TensorMap& tm) {
     load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1);
     load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1);
     load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1);
-    load_layer(c, tm, c->up2a, "upconv2.conv.0", "upconv2.conv.1", 768, 256, 1, 0, 1);
+    load_split_1x1(c, tm, c->up2y, c->up2s, "upconv2.conv.0", "upconv2.conv.1", 256, 512, 256);
     load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1);
-    load_layer(c, tm, c->up3a, "upconv3.conv.0", "upconv3.conv.1", 384, 128, 1, 0, 1);
+    load_split_1x1(c, tm, c->up3y, c->up3s, "upconv3.conv.0", "upconv3.conv.1", 128, 256, 128);
     load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1);
-    load_layer(c, tm, c->up4a, "upconv4.conv.0", "upconv4.conv.1", 192, 64, 1, 0, 1);
+    load_split_1x1(c, tm, c->up4y, c->up4s, "upconv4.conv.0", "upconv4.conv.1", 64, 128, 64);
     load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1);
     load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1);
     load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
@@ -345,9 +364,10 @@ static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
 }
 
 static void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out,
-                     int out_cs, int cout_store, bool out_f32) {
+                     int out_cs, int cout_store, bool out_f32, const Act* addup = nullptr) {
     if (c->arena.dry) return;
     ConvArgs a{};
+    if (addup) { a.addup = addup->p; a.up_H = a0.H; a.up_W = a0.W; a.up_cs = addup->C; }
     a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
     if (a1) { a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C; }
     a.N = a0.N; a.H = a0.H; a.W = a0.W;
@@ -405,12 +425,6 @@ static Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, 
     return o;
 }
 
-static Act up_act(bbocr_ctx* c, const Act& a) {
-    Act o{c->arena.alloc<uint16_t>((size_t)a.N * 4 * a.H * a.W * a.C), a.N, 2 * a.H, 2 * a.W, a.C};
-    if (!c->arena.dry) HIPCHK(launch_upsample2x(a.p, o.p, a.N, a.H, a.W, a.C, c->cur));
-    return o;
-}
-
 // ------------------------------------------------------------------------------------------------ detector
 // rgb: [nb, Himg, Wimg, 3] on a zero canvas H32 x W32 -> heat fp32 [nb, H32/2, W32/2, 2]
 static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
@@ -435,14 +449,19 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     Act f7 = conv_act(c, c->fc7, f6, false, nullptr, false, false, 1024);
     Act u1a = conv_act(c, c->up1a, f7, false, &s4, false, true, 512);              // cat([fc7, relu5_3]) -> 1x1
     Act u1b = conv_act(c, c->up1b, u1a, false, nullptr, false, true, 256);
-    Act x1 = up_act(c, u1b);
-    Act u2a = conv_act(c, c->up2a, x1, false, &s3, false, true, 256);
+    // cat([up(y), skip]) -> 1x1 + BN + ReLU, with the up-sampling commuted behind the (linear) 1x1: z = W_y y at y's
+    // resolution, then ReLU(up(z) + W_s skip + b) in the epilogue of the skip half -- up(y) is never written
+    auto up_stage = [&](const ConvPlan& py, const ConvPlan& ps, const Act& y, const Act& skip, bool relu_skip, int cout) {
+        Act z = conv_act(c, py, y, false, nullptr, false, false, cout);
+        Act o{c->arena.alloc<uint16_t>((size_t)skip.N * skip.H * skip.W * cout), skip.N, skip.H, skip.W, cout};
+        run_conv(c, ps, skip, relu_skip, nullptr, false, true, o.p, cout, cout, false, &z);
+        return o;
+    };
+    Act u2a = up_stage(c->up2y, c->up2s, u1b, s3, false, 256);
     Act u2b = conv_act(c, c->up2b, u2a, false, nullptr, false, true, 128);
-    Act x2 = up_act(c, u2b);
-    Act u3a = conv_act(c, c->up3a, x2, false, &s2, false, true, 128);
+    Act u3a = up_stage(c->up3y, c->up3s, u2b, s2, false, 128);
     Act u3b = conv_act(c, c->up3b, u3a, false, nullptr, false, true, 64);
-    Act x3 = up_act(c, u3b);
-    Act u4a = conv_act(c, c->up4a, x3, false, &s1, false, true, 64);
+    Act u4a = up_stage(c->up4y, c->up4s, u3b, s1, false, 64);
     Act u4b = conv_act(c, c->up4b, u4a, false, nullptr, false, true, 32);
     Act c1 = conv_act(c, c->cls0, u4b, false, nullptr, false, true, 32);
     Act c2 = conv_act(c, c->cls2, c1, false, nullptr, false, true, 32);

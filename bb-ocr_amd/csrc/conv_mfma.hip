@@ -25,7 +25,7 @@
 // acc[j][r]; the cout permutation of pack_conv_weights maps them to cout = tile + wn*64 + (j>>1)*32 + g*8 + (j&1)*4 + r:
 // TWO runs of 8 contiguous couts, 32 apart, so that one store instruction writes, for every pixel, 64 contiguous bytes
 // (4 lane groups x 16 B) instead of four 16-byte pieces with gaps.  v[i], i = j*4+r: run h = i>>3, position i&7.
-template <int MF>
+template <int MF, bool ADDUP = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn, int fpr,
                                               int lane, int BN, int sub = 1, int sph = 0, int spw = 0) {
     const int g = lane >> 4, pl = lane & 15;
@@ -127,6 +127,69 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             if (run1) *(u32x4*)(op + 32) = hi;
         }
     };
+    if constexpr (ADDUP) {
+        // 1x1 launch over the flattened N*up_H*up_W pixel axis whose epilogue adds up(z): F.interpolate(scale 2, bilinear,
+        // align_corners=False) of the low-resolution tensor z = a.addup -- source coordinate (o + 0.5)/2 - 0.5 clamped at 0,
+        // neighbour clamped at the far edge, four fp32 blend weights per pixel.  The 8 gather loads of fragment f+1 are issued
+        // before fragment f is blended and stored (two register sets), otherwise every fragment would wait a full L2 round trip.
+        // (launch_conv guarantees cout_store % 64 == 0 here: both runs of every lane exist.)
+        struct Gather { u32x4 q[8]; f32x2_t w[4]; };
+        const int hw = a.up_H * a.up_W, LH = a.up_H >> 1, LW = a.up_W >> 1;
+        const float rhw = 1.f / (float)hw, rw = 1.f / (float)a.up_W;
+        auto issue = [&](int f, Gather& G) {
+            int p = ox0 + (wm * MF + f) * 16 + pl;
+            p = p < a.OW ? p : a.OW - 1;                      // beyond the end: any valid address, the store is predicated
+            int ni = (int)((float)p * rhw);
+            int rem = p - ni * hw;
+            if (rem < 0) { --ni; rem += hw; } else if (rem >= hw) { ++ni; rem -= hw; }
+            int yy = (int)((float)rem * rw);
+            int xx = rem - yy * a.up_W;
+            if (xx < 0) { --yy; xx += a.up_W; } else if (xx >= a.up_W) { ++yy; xx -= a.up_W; }
+            float sy = ((float)yy + 0.5f) * 0.5f - 0.5f, sx = ((float)xx + 0.5f) * 0.5f - 0.5f;
+            sy = sy < 0.f ? 0.f : sy;
+            sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < LH - 1 ? 1 : 0), x1 = x0 + (x0 < LW - 1 ? 1 : 0);
+            const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            G.w[0] = (f32x2_t){hy * hx, hy * hx}; G.w[1] = (f32x2_t){hy * lx, hy * lx};
+            G.w[2] = (f32x2_t){ly * hx, ly * hx}; G.w[3] = (f32x2_t){ly * lx, ly * lx};
+            const uint16_t* zb = a.addup + (size_t)ni * LH * LW * a.up_cs + cout0;
+            const uint16_t* z00 = zb + ((size_t)y0 * LW + x0) * a.up_cs;
+            const uint16_t* z01 = zb + ((size_t)y0 * LW + x1) * a.up_cs;
+            const uint16_t* z10 = zb + ((size_t)y1 * LW + x0) * a.up_cs;
+            const uint16_t* z11 = zb + ((size_t)y1 * LW + x1) * a.up_cs;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                G.q[h * 4 + 0] = *(const u32x4*)(z00 + h * 32); G.q[h * 4 + 1] = *(const u32x4*)(z01 + h * 32);
+                G.q[h * 4 + 2] = *(const u32x4*)(z10 + h * 32); G.q[h * 4 + 3] = *(const u32x4*)(z11 + h * 32);
+            }
+        };
+        auto two = [](unsigned int q) { return (f32x2_t){__uint_as_float(q << 16), __uint_as_float(q & 0xffff0000u)}; };
+        Gather G[2];
+        issue(0, G[0]);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            if (f + 1 < MF) issue(f + 1, G[(f + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);               // keep the next fragment's loads ahead of this fragment's math
+            const Gather& C = G[f & 1];
+            float v[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x2_t t = two(C.q[h * 4][i]) * C.w[0];
+                    t = __builtin_elementwise_fma(two(C.q[h * 4 + 1][i]), C.w[1], t);
+                    t = __builtin_elementwise_fma(two(C.q[h * 4 + 2][i]), C.w[2], t);
+                    t = __builtin_elementwise_fma(two(C.q[h * 4 + 3][i]), C.w[3], t);
+                    const int k = h * 8 + i * 2;             // v index j*4+r == run h, position 2i / 2i+1
+                    float x0 = acc[f][k >> 2][k & 3] + bs[k] + t[0], x1 = acc[f][(k + 1) >> 2][(k + 1) & 3] + bs[k + 1] + t[1];
+                    if (a.relu_out) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                    v[k] = x0; v[k + 1] = x1;
+                }
+            store_frag(a.out, 0, a.out_cs, ox0 + (wm * MF + f) * 16, a.OW, true, v, false);
+        }
+        return;
+    }
     if (a.pool_mode == 0) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
@@ -692,7 +755,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 // BOTH operand tiles of k-step ks+RING-1 are issued by LDS-DMA at k-step ks (weights: lane-linear slice; activations: wave w
 // gathers channel group w of 256 consecutive pixels, 16 B per lane), and the barrier waits with the constant counted
 // vmcnt((RING-2) * DMAs-per-k-step).  No halo, so the tile is simply 256 consecutive pixels of N*H*W.
-template <int WM, int WN, int MF, int RING>
+template <int WM, int WN, int MF, int RING, bool ADDUP>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the activation tile");
@@ -773,19 +836,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const Conv
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         slot = slot + 1 == RING ? 0 : slot + 1;
     }
-    conv_epilogue<MF>(a, acc, 0, nt, 0, px0, wm, wn, 16, lane, BN);
+    conv_epilogue<MF, ADDUP>(a, acc, 0, nt, 0, px0, wm, wn, 16, lane, BN);
 }
 
-template <int WM, int WN, int MF>
-static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
+template <int WM, int WN, int MF, bool ADDUP>
+static hipError_t launch_dma1x1_k(const ConvArgs& a, long long grid, hipStream_t s) {
     constexpr int RING = 3, NPX = WM * MF * 16;
-    const long long total = (long long)a.N * a.H * a.W;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    a.N = 1; a.OH = 1; a.OW = (int)total; a.TH = 1; a.TW = NPX; a.tiles_y = 1;
-    a.tiles_x = (int)((total + NPX - 1) / NPX);
-    const long long grid = (long long)a.tiles_x * a.ntiles_n;
-    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    auto k = conv1x1_dma_kernel<WM, WN, MF, RING>;
+    auto k = conv1x1_dma_kernel<WM, WN, MF, RING, ADDUP>;
     const size_t smem = (size_t)RING * ((size_t)WN * 64 * 64 + (size_t)NPX * 64);
     static bool attr = false;
     if (!attr) {
@@ -795,6 +852,19 @@ static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3((int)grid), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError();
+}
+
+template <int WM, int WN, int MF>
+static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
+    constexpr int NPX = WM * MF * 16;
+    const long long total = (long long)a.N * a.H * a.W;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.N = 1; a.OH = 1; a.OW = (int)total; a.TH = 1; a.TW = NPX; a.tiles_y = 1;
+    a.tiles_x = (int)((total + NPX - 1) / NPX);
+    const long long grid = (long long)a.tiles_x * a.ntiles_n;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    // the epilogue that adds an up-sampled tensor is its own instantiation: its register needs must not leak into the others
+    return a.addup ? launch_dma1x1_k<WM, WN, MF, true>(a, grid, s) : launch_dma1x1_k<WM, WN, MF, false>(a, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1000,6 +1070,9 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
+    if (a.addup && !(small && conv_dma() && p.KH == 1 && p.KW == 1 && a.zero && !a.pool_mode && !a.out_f32 && !a.tail && a.cout_store % 64 == 0 &&
+                     a.cout_store == p.Cout_pad))
+        return hipErrorInvalidValue;
     if (small && conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
         return BN == 128 ? launch_dma1x1<2, 2, 8>(a, s) : launch_dma1x1<4, 1, 4>(a, s);
     if (small && conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {

@@ -157,51 +157,6 @@ hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ bilinear x2
-// F.interpolate(scale 2, mode='bilinear', align_corners=False): src = (dst+0.5)/2-0.5 clamped at 0, lambda in fp32.
-__global__ void __launch_bounds__(256) upsample2x_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N, int H, int W,
-                                                         int C8) {
-    const int OH = 2 * H, OW = 2 * W;
-    const size_t total = (size_t)N * OH * OW * C8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        size_t r = i / C8;
-        const int ox = (int)(r % OW);
-        r /= OW;
-        const int oy = (int)(r % OH);
-        const int n = (int)(r / OH);
-        float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
-        float sx = ((float)ox + 0.5f) * 0.5f - 0.5f;
-        sy = sy < 0.f ? 0.f : sy;
-        sx = sx < 0.f ? 0.f : sx;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const uint16_t* b = in + (size_t)n * H * W * C8 * 8 + (size_t)c8 * 8;
-        const u32x4 v00 = *(const u32x4*)(b + ((size_t)y0 * W + x0) * C8 * 8);
-        const u32x4 v01 = *(const u32x4*)(b + ((size_t)y0 * W + x1) * C8 * 8);
-        const u32x4 v10 = *(const u32x4*)(b + ((size_t)y1 * W + x0) * C8 * 8);
-        const u32x4 v11 = *(const u32x4*)(b + ((size_t)y1 * W + x1) * C8 * 8);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = hy * (hx * bf16lo(v00[j]) + lx * bf16lo(v01[j])) + ly * (hx * bf16lo(v10[j]) + lx * bf16lo(v11[j]));
-            const float hi = hy * (hx * bf16hi(v00[j]) + lx * bf16hi(v01[j])) + ly * (hx * bf16hi(v10[j]) + lx * bf16hi(v11[j]));
-            o[j] = pack_bf16x2(lo, hi);
-        }
-        *(u32x4*)(out + i * 8) = o;
-    }
-}
-
-hipError_t launch_upsample2x(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t s) {
-    if (C & 7) return hipErrorInvalidValue;
-    const size_t total = (size_t)N * 4 * H * W * (C / 8);
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, in, out, N, H, W, C / 8);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------ gray
 // cv2 BGR2GRAY fixed point applied to channels as given (upstream applies it to whatever 3-channel array it holds).
 __global__ void __launch_bounds__(256) gray_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t npix) {

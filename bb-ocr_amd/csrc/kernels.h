@@ -28,6 +28,11 @@ struct ConvArgs {
     const uint16_t* tail_frag;
     int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
+    // non-null: add the 2x bilinear up-sampling (align_corners=False) of this bf16 NHWC tensor [N, up_H/2, up_W/2, up_cs] to the
+    // accumulators before bias/ReLU -- conv1x1(cat[up(y), s]) == up(conv1x1_y(y)) + conv1x1_s(s): the U-net 1x1 layers never
+    // materialise up(y).  up_H/up_W: size of the (full-resolution) output image; plain store path only.
+    const uint16_t* addup;
+    int up_H, up_W, up_cs;
     unsigned long long* stamps;   // diagnostic (BBOCR_CONV_STAMPS): per workgroup {t_start, t_prologue, t_mainloop, t_end} s_memtime; null in production
 };
 
@@ -52,7 +57,6 @@ hipError_t launch_conv1_1(const uint8_t* rgb, int N, int Himg, int Wimg, int H32
 void pack_conv1_1_weights(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/);
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
-hipError_t launch_upsample2x(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
 hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw, hipStream_t s);
 
