@@ -499,22 +499,31 @@ static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, c
     if (B <= 0 || H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad page batch shape");
     const DetDims d = det_dims(H, W, p.canvas_size, p.mag_ratio);
     if (d.th <= 0 || d.tw <= 0) fail(BBOCR_ERR_ARG, "page collapses to zero size");
-    // pages per detector pass: as many as fit a 40 GB activation arena (sized by a dry run on one page), at most 32
-    int sb = c->cfg.det_sub_batch;
-    if (sb <= 0) {
+    // Pages per detector pass.  Explicit det_sub_batch: uniform passes of that size.  Auto: passes as large as a 96 GB
+    // activation arena allows (sized by a dry run on one page; at most 64 pages), and -- when the caller overlaps box
+    // extraction with the next pass (readtext_batch) -- a short last pass of 8 pages, because only the LAST pass's
+    // CCL + host geometry is exposed: 64 pages run as [56, 8].
+    std::vector<int> passes;
+    if (c->cfg.det_sub_batch > 0) {
+        for (int b0 = 0; b0 < B; b0 += c->cfg.det_sub_batch) passes.push_back(std::min(c->cfg.det_sub_batch, B - b0));
+    } else {
         c->arena.begin(true);
         craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
         const size_t per_page = std::max<size_t>(c->arena.off, 1);
-        sb = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)40 << 30) / per_page));
+        const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)96 << 30) / per_page));
+        const int tail = (after_sub && B >= 24 && cap > 8) ? 8 : 0;
+        const int body = B - tail, nbig = cdiv(body, cap);
+        for (int i = 0; i < nbig; ++i) passes.push_back(body / nbig + (i < body % nbig ? 1 : 0));
+        if (tail) passes.push_back(tail);
     }
-    sb = std::min(sb, B);
+    const int sb = *std::max_element(passes.begin(), passes.end());
     const bool need_resize = (d.th != H || d.tw != W);
     if (need_resize) c->resized.ensure((size_t)sb * d.th * d.tw * 3);
     c->arena.begin(true);
     craft_forward(c, nullptr, sb, d.th, d.tw, d.H32, d.W32, nullptr);
     c->arena.buf.ensure(c->arena.off);
-    for (int b0 = 0; b0 < B; b0 += sb) {
-        const int nb = std::min(sb, B - b0);
+    int b0 = 0;
+    for (const int nb : passes) {
         const uint8_t* src = rgb + (size_t)b0 * H * W * 3;
         if (need_resize) {
             HIPCHK(launch_resize_u8(src, nb, H, W, 3, (uint8_t*)c->resized.p, d.th, d.tw, c->stream));
@@ -523,6 +532,7 @@ static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, c
         c->arena.begin(false);
         craft_forward(c, src, nb, d.th, d.tw, d.H32, d.W32, heat + (size_t)b0 * d.h * d.w * 2);
         if (after_sub) after_sub(b0, nb);   // everything of this sub-batch is enqueued (nothing has been waited for)
+        b0 += nb;
     }
 }
 
