@@ -102,6 +102,7 @@ struct bbocr_ctx {
     // ---- detector
     bool craft_loaded = false;
     uint16_t* c11_w = nullptr;
+    uint16_t* c11_wf = nullptr;               // conv1_1 weights in the layout of the producer fused into conv1_2
     float* c11_b = nullptr;
     ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
     ConvPlan up1a, up1b, up2b, up3b, up4b, cls0, cls2, cls4;
@@ -237,6 +238,8 @@ static void load_craft(bbocr_ctx* c, const TensorMap& tm) {
         std::vector<uint16_t> pk(2 * 4 * 64 * 8);
         pack_conv1_1_weights(w.data(), pk.data());
         c->c11_w = upload(c, pk);
+        pack_conv1_1_weights_fused(w.data(), pk.data());
+        c->c11_wf = upload(c, pk);
         c->c11_b = upload(c, b);
     }
     load_layer(c, tm, c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1);
@@ -401,8 +404,9 @@ static Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, 
 
 // conv with the max-pool fused into its epilogue.  mode 1 = MaxPool2d(2,2), 2 = MaxPool2d((2,1),(2,1)).  Returns the pooled
 // activation; when `full` is given the un-pooled conv output (bias, relu_out) is written too (U-net skip tensors).
+struct RgbSource { const uint8_t* rgb; int Himg, Wimg; };   // conv1_2 with conv1_1 fused in: a0 then only carries the canvas shape
 static Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, bool relu_out, int store, int mode, bool pool_relu,
-                         Act* full) {
+                         Act* full, const RgbSource* rgb = nullptr) {
     const int OH = a0.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a0.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     const int PH = OH / 2, PW = mode == 1 ? OW / 2 : OW;
     if (full) *full = Act{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * store), a0.N, OH, OW, store};
@@ -414,6 +418,7 @@ static Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool re
     a.relu_in0 = relu0; a.relu_out = relu_out; a.out_f32 = 0;
     a.out = full ? (void*)full->p : nullptr; a.out_cs = store; a.cout_store = store;
     a.pool_mode = mode; a.pool_relu = pool_relu; a.store_full = full != nullptr; a.pool_cs = store; a.pool_out = o.p;
+    if (rgb) { a.in0 = (const uint16_t*)rgb->rgb; a.c11_w = c->c11_wf; a.c11_b = c->c11_b; a.rgb_H = rgb->Himg; a.rgb_W = rgb->Wimg; }
     launch_conv_profiled(c, p, a);
     return o;
 }
@@ -430,9 +435,19 @@ static Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, 
 static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
     Arena& ar = c->arena;
     c->prof_group = 0;
-    Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
-    if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->cur));
-    Act p1 = conv_pool_act(c, c->conv1_2, a1, false, true, 64, 1, false, nullptr);          // conv1_2+BN+ReLU+pool fused
+    // normalise + conv1_1 + ReLU are produced inside conv1_2's prologue (its 64-channel input never reaches HBM);
+    // BBOCR_FUSE1=0 runs conv1_1 as its own kernel (A/B runs)
+    static const bool fuse1 = [] { const char* e = getenv("BBOCR_FUSE1"); return !(e && e[0] == '0'); }();
+    Act p1;
+    if (fuse1) {
+        const Act canvas{nullptr, nb, H32, W32, 64};
+        const RgbSource src{rgb, Himg, Wimg};
+        p1 = conv_pool_act(c, c->conv1_2, canvas, false, true, 64, 1, false, nullptr, &src);
+    } else {
+        Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
+        if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->cur));
+        p1 = conv_pool_act(c, c->conv1_2, a1, false, true, 64, 1, false, nullptr);          // conv1_2+BN+ReLU+pool fused
+    }
     Act a3 = conv_act(c, c->conv2_1, p1, false, nullptr, false, true, 128);
     Act s1;                                                                        // slice1 ends on BatchNorm (skip tensor),
     Act p2 = conv_pool_act(c, c->conv2_2, a3, false, false, 128, 1, true, &s1);   // slice2 opens with ReLU + pool: both fused

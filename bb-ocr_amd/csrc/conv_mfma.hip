@@ -571,7 +571,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 //     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
 // vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
 // issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64>
+// FUSE1 (CRAFT conv1_2 only: Cin = 64, 16x16 tiles, BN = 64): the 64-channel input patch is not read from memory but PRODUCED
+// in the prologue from the uint8 RGB page -- normalizeMeanVariance + conv1_1 (3x3, 3->64) + BN + ReLU, one 27-deep (padded
+// to 64) MFMA product per 16 patch pixels -- and written straight into the two LDS patch buffers (both 32-channel chunks are
+// resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -635,7 +639,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     stamp(0);
     Geo cur;
     geom(tile, cur);
-    geom_pix(cur);
+    if constexpr (!FUSE1) geom_pix(cur);
 
     auto issue_p = [&](int sp, int chunk, int par, auto pb_c) {
         constexpr int pb = decltype(pb_c)::value;
@@ -668,7 +672,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 
     // patch DMA schedule inside a chunk: PCNT(tap) blocks at tap (first taps take two while NPB > PSLOTS)
     struct Sched {
-        static constexpr int pcnt(int tap) { return tap >= PSLOTS ? 0 : ((NPB - PSLOTS > tap ? 2 : 1) * (tap < (NPB > PSLOTS ? PSLOTS : NPB) ? 1 : 0)); }
+        static constexpr int pcnt(int tap) {
+            if (FUSE1) return 0;
+            return tap >= PSLOTS ? 0 : ((NPB - PSLOTS > tap ? 2 : 1) * (tap < (NPB > PSLOTS ? PSLOTS : NPB) ? 1 : 0));
+        }
         static constexpr int pfirst(int tap) { int s = 0; for (int t = 0; t < tap; ++t) s += pcnt(t); return s; }
         static constexpr int wcnt(bool more, int tap) { return (more || tap < 9 - (RING - 1)) ? WPT : 0; }
         // operations younger than slice ks+1 at the end of tap `tap` of a chunk of kind `more` (previous chunk: kind true)
@@ -684,13 +691,86 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             return nv;
         }
     };
-    static_assert(Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
+    static_assert(FUSE1 || Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
 
     // prologue: first RING-1 weight slices + the whole first patch of the first tile
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i)
         if (i < nk) issue_w(cur.wsrc + (size_t)i * WBUF, i);
-    [&]<int... PB>(std::integer_sequence<int, PB...>) { (issue_p(spix[PB], 0, 0, std::integral_constant<int, PB>{}), ...); }(std::make_integer_sequence<int, NPB>{});
+    if constexpr (!FUSE1) {
+        [&]<int... PB>(std::integer_sequence<int, PB...>) { (issue_p(spix[PB], 0, 0, std::integral_constant<int, PB>{}), ...); }(std::make_integer_sequence<int, NPB>{});
+    } else {
+        static_assert(!FUSE1 || (RING == 3 && BN == 64 && NPS == 324), "fused conv1_1 producer: 16x16 tiles, 3-deep ring of 4 KB slices");
+        // (1) normalised RGB patch 20 x 20 (tile + 2-pixel halo) as 4 x bf16 per pixel into ring slot 2, which receives its first
+        //     weight slice only at k-step 0.  Canvas semantics of detector_input: pixels of the H x W canvas beyond the page are
+        //     raw zeros (normalised like any pixel), pixels beyond the canvas are conv1_1's zero padding.
+        u32x2* const rgbp = (u32x2*)(wbuf + 2 * WBUF);
+        const uint8_t* rgb = (const uint8_t*)a.in0;
+        const float m0 = 0.485f * 255.0f, m1 = 0.456f * 255.0f, m2 = 0.406f * 255.0f;
+        const float s0 = 0.229f * 255.0f, s1 = 0.224f * 255.0f, s2 = 0.225f * 255.0f;
+        for (int p = tid; p < 400; p += NT) {
+            const int py = p / 20, px = p - py * 20;
+            const int iy = cur.oy0 - 2 + py, ix = cur.ox0 - 2 + px;
+            u32x2 v = {0u, 0u};
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                float r = 0.f, g = 0.f, b = 0.f;
+                if (iy < a.rgb_H && ix < a.rgb_W) {
+                    const uint8_t* q = rgb + ((size_t)(cur.n * a.rgb_H + iy) * a.rgb_W + ix) * 3;
+                    r = (float)q[0]; g = (float)q[1]; b = (float)q[2];
+                }
+                v[0] = pack_bf16x2((r - m0) / s0, (g - m1) / s1);
+                v[1] = pack_bf16x2((b - m2) / s2, 0.f);
+            }
+            rgbp[p] = v;
+        }
+        // conv1_1 weights as MFMA A fragments: K = tap*4 + channel padded to 64 (two k-steps), couts in the run order of the
+        // epilogue mapping, so that a lane's 16 outputs are exactly one 16-byte slot of each 32-channel chunk of the patch image
+        bf16x8 w1[2][4];
+#pragma unroll
+        for (int ks1 = 0; ks1 < 2; ++ks1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w1[ks1][j] = *(const bf16x8*)(a.c11_w + ((size_t)(ks1 * 4 + j) * 64 + lane) * 8);
+        const int g = lane >> 4, pl = lane & 15;
+        float b1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b1[i] = a.c11_b[(i >> 3) * 32 + g * 8 + (i & 7)];
+        __syncthreads();
+        // (2) 21 fragments of 16 patch pixels (18 x 18 = 324 = 20*16 + 4), dealt round-robin to the four waves
+        for (int fi = wave; fi < 21; fi += NW) {
+            const int pp = fi * 16 + pl;
+            const int py = pp / 18, px = pp - py * 18;           // patch pixel -> its 3x3 window starts at (py, px) of the RGB patch
+            f32x4 d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks1 = 0; ks1 < 2; ++ks1) {
+                int t0 = ks1 * 8 + 2 * g, t1 = t0 + 1;
+                t0 = t0 > 8 ? 8 : t0;                            // taps >= 9 meet zero weights; any valid address will do
+                t1 = t1 > 8 ? 8 : t1;
+                const int pc = pp < 324 ? py * 20 + px : 0;
+                const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
+                const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ks1][j], bfr, d[j], 0, 0, 0);
+            }
+            const int iy = cur.oy0 - 1 + py, ix = cur.ox0 - 1 + px;
+            const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;     // else: conv1_2's own zero padding
+            if (pp < 324) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = h * 8 + i * 2;
+                        const float x0 = fmaxf(d[k >> 2][k & 3] + b1[k], 0.f), x1 = fmaxf(d[(k + 1) >> 2][(k + 1) & 3] + b1[k + 1], 0.f);
+                        o[i] = inside ? pack_bf16x2(x0, x1) : 0u;
+                    }
+                    *(u32x4*)(pbuf + h * patch_bytes + (g * NP + pp) * 16) = o;
+                }
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamp(1);
 
@@ -940,9 +1020,9 @@ static const char* conv_stamps_dir() {
     return d;
 }
 
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64>
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS>;
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS, FUSE1>;
     const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     static bool attr = false;
     if (!attr) {
@@ -984,6 +1064,10 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
         // BN = 64: k-steps are short (16 MFMAs per wave), what pays is a THIRD co-resident workgroup: 16x16 tiles with the patch
         // trimmed to its 18 x 18 = 324 pixels and a 3-deep weight ring are 53,760 B of LDS (3 x 53,760 <= 160 KB)
         static const bool three = [] { const char* e = getenv("BBOCR_CONV_3WG"); return !(e && e[0] == '0'); }();
+        if (a.c11_w) {   // conv1_2 with the conv1_1 producer fused in
+            if (!(npb == 6 && a.PH * a.PW == 324 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
+            return launch_dma_one<WM, WN, MF, 6, 3, 324, true>(a, grid, s);
+        }
         if (three && npb == 6 && a.PH * a.PW == 324) return launch_dma_one<WM, WN, MF, 6, 3, 324>(a, grid, s);
         if (npb == 6) return launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
     }

@@ -25,6 +25,24 @@ void pack_conv1_1_weights(const float* w, uint16_t* out) {
             }
 }
 
+// variant for the producer fused into conv1_2 (conv_mfma.hip): fragment nf, row -> cout (nf>>1)*32 + (row>>2)*8 + (nf&1)*4 + (row&3)
+void pack_conv1_1_weights_fused(const float* w, uint16_t* out) {
+    size_t o = 0;
+    for (int s = 0; s < 2; ++s)
+        for (int nf = 0; nf < 4; ++nf)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 15;
+                const int cout = (nf >> 1) * 32 + (row >> 2) * 8 + (nf & 1) * 4 + (row & 3);
+                for (int j = 0; j < 8; ++j) {
+                    const int k = s * 32 + 8 * (l >> 4) + j;
+                    const int tap = k >> 2, ch = k & 3;
+                    float v = 0.f;
+                    if (tap < 9 && ch < 3) v = w[((size_t)cout * 3 + ch) * 9 + tap];
+                    out[o++] = f32_to_bf16_host(v);
+                }
+            }
+}
+
 __global__ void __launch_bounds__(256) conv1_1_kernel(const uint8_t* __restrict__ rgb, int Himg, int Wimg, int H32, int W32,
                                                       const uint16_t* __restrict__ wpk, const float* __restrict__ bias,
                                                       uint16_t* __restrict__ out, int tiles_x, int tiles_y) {

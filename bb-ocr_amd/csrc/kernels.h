@@ -33,6 +33,11 @@ struct ConvArgs {
     // materialise up(y).  up_H/up_W: size of the (full-resolution) output image; plain store path only.
     const uint16_t* addup;
     int up_H, up_W, up_cs;
+    // non-null: CRAFT conv1_2 with conv1_1 fused in -- in0 is the uint8 RGB batch [N, rgb_H, rgb_W, 3] on the H x W canvas,
+    // c11_w the conv1_1 weights packed by pack_conv1_1_weights_fused, c11_b its 64 biases (C0 stays 64)
+    const uint16_t* c11_w;
+    const float* c11_b;
+    int rgb_H, rgb_W;
     unsigned long long* stamps;   // diagnostic (BBOCR_CONV_STAMPS): per workgroup {t_start, t_prologue, t_mainloop, t_end} s_memtime; null in production
 };
 
@@ -55,6 +60,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zer
 hipError_t launch_conv1_1(const uint8_t* rgb, int N, int Himg, int Wimg, int H32, int W32, const uint16_t* wpk, const float* bias,
                           uint16_t* out, hipStream_t s);
 void pack_conv1_1_weights(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/);
+void pack_conv1_1_weights_fused(const float* w, uint16_t* out);   // same K order, couts in the conv epilogue's run order
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
