@@ -87,6 +87,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
     // 128-byte lines (8 pixels x 128 B) instead of 16 half lines: the CU's store path is priced per line touched
     // (tools/micro/store_patterns.hip: 64-KB tile burst 5.9k -> 3.9k cycles).
     const bool fullw = !a.out_f32 && nt * BN + wn * 64 + 64 <= a.cout_store;   // wave-uniform
+    int spw_cur = spw;                                                         // x phase of the fragment row being stored
     auto pack_runs = [&](const float (&v)[16], u32x4& lo, u32x4& hi) {
         lo = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         hi = (u32x4){pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
@@ -103,13 +104,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 dB[i] = (unsigned)__builtin_amdgcn_update_dpp((int)hi[i], (int)lo[i], 0x108 /*row_shl:8*/, 0xF, 0x3, false);
             }
             const int co = cout0 + (pl >> 3) * 32;
-            const int xA = (xb + (pl & 7)) * sub + spw, xB = (xb + 8 + (pl & 7)) * sub + spw;
+            const int xA = (xb + (pl & 7)) * sub + spw_cur, xB = (xb + 8 + (pl & 7)) * sub + spw_cur;
             uint16_t* op = (uint16_t*)base + row + co;
             if (row_ok && xA < xlim) *(u32x4*)(op + (size_t)xA * cs) = dA;
             if (row_ok && xB < xlim) *(u32x4*)(op + (size_t)xB * cs) = dB;
             return;
         }
-        const int x = (xb + pl) * sub + spw;
+        const int x = (xb + pl) * sub + spw_cur;
         if (!(row_ok && x < xlim)) return;
         if (f32) {
             float* op = (float*)base + row + (size_t)x * cs + cout0;
@@ -195,8 +196,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
         for (int f = 0; f < MF; ++f) {
             const int F = wm * MF + f;
             const int fr = F / fpr, fc = F - fr * fpr;
-            // sub > 1: the tile lives on one phase (sph, spw) of the dilation lattice (dilated conv run as sub*sub plain convs)
-            const int oy = (oy0 + fr) * sub + sph;
+            // sub > 1: dilated conv run as sub*sub plain convs on the phase sub-lattices, whose images are stacked along y
+            // (a.stack rows + one zero row each): tile row -> phase (sph, spw) and row inside the phase image
+            int oy = oy0 + fr;
+            bool rowok = true;
+            if (sub > 1) {
+                const int q = oy / (a.stack + 1);
+                const int ly = oy - q * (a.stack + 1);
+                const int ph = q / sub;
+                spw_cur = q - ph * sub;
+                rowok = ly < a.stack && q < sub * sub;
+                oy = ly * sub + ph;
+            }
             float v[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -206,7 +217,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                     if (a.relu_out) x = fmaxf(x, 0.f);
                     v[j * 4 + r] = x;
                 }
-            store_frag(a.out, (size_t)(n * a.OH + oy) * a.OW * a.out_cs, a.out_cs, ox0 + fc * 16, a.OW, oy < a.OH, v, a.out_f32);
+            store_frag(a.out, (size_t)(n * a.OH + oy) * a.OW * a.out_cs, a.out_cs, ox0 + fc * 16, a.OW, rowok && oy < a.OH, v, a.out_f32);
         }
         return;
     }
@@ -614,23 +625,35 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         const int ty = id % a.tiles_y;
         int n = id / a.tiles_y;
         g.sph = 0; g.spw = 0;
-        if (sub > 1) { g.spw = n % sub; n /= sub; g.sph = n % sub; n /= sub; }
-        g.n = n;
+        g.n = n;     // (sub > 1: all sub*sub phase images of page n are stacked along y inside the tile grid, see geom_pix)
         g.oy0 = ty * a.TH; g.ox0 = tx * a.TW;
         g.wsrc = (const unsigned char*)a.wpk + (size_t)g.nt * nk * WBUF;
     };
     // per-lane source pixel of each 64-pixel patch block (or -1: padding -> zero page)
     int spix[NPB];
     const int pw_magic = (65536 + a.PW - 1) / a.PW;     // pix / PW == (pix * magic) >> 16 exactly for pix < 448, PW <= 66
+    const int stack_magic = (65536 + a.stack) / (a.stack + 1);   // same bound for the stacked phase images (checked by launch_conv)
     auto geom_pix = [&](const Geo& g) {
         const int iy0 = g.oy0 - 1, ix0 = g.ox0 - 1;
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             const int pix = pb * 64 + lane;
             const int py = (pix * pw_magic) >> 16, px = pix - py * a.PW;
-            const int ly = iy0 + py, lx = ix0 + px;                 // sub-lattice coordinates
-            const int iy = ly * sub + g.sph, ix = lx * sub + g.spw;
-            spix[pb] = (py < a.PH && ly >= 0 && iy < a.H && lx >= 0 && ix < a.W) ? (g.n * a.H + iy) * a.W + ix : -1;
+            int ly = iy0 + py;
+            const int lx = ix0 + px;                                // sub-lattice coordinates
+            int sph = 0, spw = 0;
+            bool rowok = ly >= 0;
+            if (sub > 1) {
+                // virtual row -> (phase q, row inside the phase image); row a.stack of every phase is the shared zero row
+                const int vy = ly < 0 ? 0 : ly;
+                const int q = (vy * stack_magic) >> 16;
+                ly = vy - q * (a.stack + 1);
+                sph = q / sub;
+                spw = q - sph * sub;
+                rowok = rowok && ly < a.stack && q < sub * sub;
+            }
+            const int iy = ly * sub + sph, ix = lx * sub + spw;
+            spix[pb] = (py < a.PH && rowok && iy < a.H && lx >= 0 && ix < a.W) ? (g.n * a.H + iy) * a.W + ix : -1;
         }
     };
     auto stamp = [&](int i) {   // diagnostic build of the tile timeline; a.stamps is null in production
@@ -1104,22 +1127,26 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
         for (int th = 16; th >= 4; th >>= 1) {
             const int tw = 256 / th, ph = th + 2, pw = tw + 2, npb = cdiv(ph * pw, 64);
             if (npb != 6 && npb != 7) continue;
-            const long long cost = (long long)cdiv(LH, th) * cdiv(LW, tw);
+            // the d*d phase images of a page are stacked along y with one zero row between them (it is the padding row of both
+            // neighbours), so that tiles do not end at every 10-row phase image: fc6 fills 80 % of its MFMA rows instead of 55 %
+            const long long cost = (long long)cdiv(d * d * (LH + 1), th) * cdiv(LW, tw);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = npb * 64; }
         }
-        if (best > 0 && (a.C0 + a.C1 == p.Cin_pad) && !(a.C0 & 31) && !(a.C1 & 31)) {
+        if (best > 0 && (a.C0 + a.C1 == p.Cin_pad) && !(a.C0 & 31) && !(a.C1 & 31) && d * d * (LH + 1) + 18 < 448 && LH + 1 <= 66) {
             a.sub = d;
+            a.stack = LH;
             a.tiles_x = cdiv(LW, a.TW);
-            a.tiles_y = cdiv(LH, a.TH);
+            a.tiles_y = cdiv(d * d * (LH + 1), a.TH);
             a.ntiles_n = p.Cout_pad / BN;
             a.nchunks = p.Cin_pad / 32;
             a.wpk = p.d_w;
             a.bias = p.d_b;
             a.dbg = 0;
-            const long long g = (long long)a.N * d * d * a.tiles_x * a.tiles_y * a.ntiles_n;
+            const long long g = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
             if (g > 0 && g <= 0x7fffffffLL)
                 return BN == 128 ? launch_dma<2, 2, 8>(a, a.NP / 64, (int)g, s) : launch_dma<4, 1, 4>(a, a.NP / 64, (int)g, s);
             a.sub = 1;
+            a.stack = 0;
         }
     }
     const int ring = 2;

@@ -27,6 +27,7 @@ struct ConvArgs {
                            // cout_store 16): {b1[16], w2[32], b2[2]}; tail_frag: W1 as a bf16 MFMA A fragment [64 lanes][8]
     const uint16_t* tail_frag;
     int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
+    int stack;             // sub > 1: rows of one phase image; the sub*sub images of a page are stacked along y, one zero row apart
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
     // non-null: add the 2x bilinear up-sampling (align_corners=False) of this bf16 NHWC tensor [N, up_H/2, up_W/2, up_cs] to the
     // accumulators before bias/ReLU -- conv1x1(cat[up(y), s]) == up(conv1x1_y(y)) + conv1x1_s(s): the U-net 1x1 layers never

@@ -1,12 +1,13 @@
 """Per-layer table of the detector from a rocprofv3 --kernel-trace CSV (tools/detect_only.py run): duration and TFLOP/s."""
 import csv, sys
-MACS = [('conv1_2',45.298),('conv2_1',22.649),('conv2_2',45.298),('conv3_1',22.649),('conv3_2',45.298),('conv3_3',45.298),('conv4_1',22.649),
+MACS = [('conv1_2',45.298 + 2.123),('conv2_1',22.649),('conv2_2',45.298),('conv3_1',22.649),('conv3_2',45.298),('conv3_3',45.298),('conv4_1',22.649),
         ('conv4_2',45.298),('conv4_3',45.298),('conv5_1',11.325),('conv5_2',11.325),('fc6',22.649),('fc7',5.033),('up1a',3.775),('up1b',5.662),
         ('up2y',0.315),('up2s',2.517),('up2b',5.662),('up3y',0.315),('up3s',2.517),('up3b',5.662),('up4y',0.315),('up4s',2.517),('up4b',5.662),('cls0',2.831),('cls2',2.831),('cls4',1.416)]
 path, npages = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('conv1_1_kernel')]
+# a detector pass starts at conv1_1 (BBOCR_FUSE1=0) or at the fused conv1_2 launch (the only <..., true> 3x3 instantiation)
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('conv1_1_kernel') or ('conv3x3_dma' in r['Kernel_Name'] and 'true>' in r['Kernel_Name'])]
 start = idx[-1]
 k = 0; tot = 0.0; other = 0.0
 for r in rows[start:]:
