@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbbocr.so")
+LIB_PATH = os.environ.get("BBOCR_LIB_PATH") or os.path.join(_HERE, "libbbocr.so")   # override: A/B runs of two builds on one box
 
 
 class bbocr_config(C.Structure):

@@ -296,20 +296,32 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         [&]<int... V>(std::integer_sequence<int, V...>) { (visit(std::integral_constant<int, V>{}), ...); }(std::make_integer_sequence<int, 64>{});
         stream_head();               // next step's first fragments travel while the gate math runs
         __builtin_amdgcn_sched_barrier(0);
+        // gate math on PAIRS of sequences (v_pk_mul/add/fma_f32): the step is VALU-bound, and only the exp2/rcp stay scalar
         auto gate_group = [&](auto a_c) {
             constexpr int a = decltype(a_c)::value;
             const int unit = wave * 32 + a * 16 + u;
+            auto ex2 = [](f32x2_t x) { return (f32x2_t){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; };
+            auto rcp2 = [](f32x2_t x) { return (f32x2_t){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; };
+            const f32x2_t one = {1.f, 1.f}, nl = {-1.442695041f, -1.442695041f}, l2 = {2.885390082f, 2.885390082f}, m2 = {-2.f, -2.f};
+            auto sig2 = [&](f32x2_t x) { return rcp2(one + ex2(x * nl)); };
+            auto tanh2 = [&](f32x2_t x) { return __builtin_elementwise_fma(rcp2(one + ex2(x * l2)), m2, one); };   // 1 - 2/(1+e^{2x}), exact fma
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned int w0 = xq[r][a * 2], w1 = xq[r][a * 2 + 1];
-                const float gi = acc[a][0][r] + __uint_as_float(w0 << 16);
-                const float gf = acc[a][1][r] + __uint_as_float(w0 & 0xffff0000u);
-                const float gg = acc[a][2][r] + __uint_as_float(w1 << 16);
-                const float go = acc[a][3][r] + __uint_as_float(w1 & 0xffff0000u);
-                const float cn = sigmoid_f(gf) * c[a][r] + sigmoid_f(gi) * tanh_f(gg);
-                c[a][r] = cn;
-                const float hv = sigmoid_f(go) * tanh_f(cn);
-                *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
+            for (int rp = 0; rp < 4; rp += 2) {
+                const unsigned int a0 = xq[rp][a * 2], a1 = xq[rp][a * 2 + 1], b0 = xq[rp + 1][a * 2], b1 = xq[rp + 1][a * 2 + 1];
+                const f32x2_t gi = (f32x2_t){acc[a][0][rp], acc[a][0][rp + 1]} + (f32x2_t){__uint_as_float(a0 << 16), __uint_as_float(b0 << 16)};
+                const f32x2_t gf = (f32x2_t){acc[a][1][rp], acc[a][1][rp + 1]} +
+                                   (f32x2_t){__uint_as_float(a0 & 0xffff0000u), __uint_as_float(b0 & 0xffff0000u)};
+                const f32x2_t gg = (f32x2_t){acc[a][2][rp], acc[a][2][rp + 1]} + (f32x2_t){__uint_as_float(a1 << 16), __uint_as_float(b1 << 16)};
+                const f32x2_t go = (f32x2_t){acc[a][3][rp], acc[a][3][rp + 1]} +
+                                   (f32x2_t){__uint_as_float(a1 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+                const f32x2_t cp = {c[a][rp], c[a][rp + 1]};
+                const f32x2_t cn = sig2(gf) * cp + sig2(gi) * tanh2(gg);
+                c[a][rp] = cn[0];
+                c[a][rp + 1] = cn[1];
+                const f32x2_t hv = sig2(go) * tanh2(cn);
+                unsigned char* hp = hn + ((unit >> 3) * 16 + g * 4 + rp) * 16 + (unit & 7) * 2;
+                *(unsigned short*)(hp) = f32_to_bf16_bits(hv[0]);
+                *(unsigned short*)(hp + 16) = f32_to_bf16_bits(hv[1]);
             }
         };
         gate_group(std::integral_constant<int, 0>{});
