@@ -148,10 +148,19 @@ def main():
         "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stage.items()},
     }
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of the
+    # same detector, reads = 2 x FETCH_SIZE KiB on gfx950), scaled by the pages the average launch of THIS run processed
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")
+    if os.path.exists(pmc) and conv_launches > 0 and (args.width, args.height) == (1280, 960):
+        with open(pmc) as f:
+            t = json.load(f)
+        traffic = (t["read_MB_per_page"] + t["write_MB_per_page"]) * 1e6 * B * args.steps / conv_launches
+        traffic_src = f"profiles/r01_pmc_hbm.json ({t['read_MB_per_page']:.0f} MB read + {t['write_MB_per_page']:.0f} MB written per page; bytes per average launch)"
     result["roofline"] = {
-        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel (detector launches conv1_2..conv_cls.4, 24 per sub-batch)",
+        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel (all 27 detector launches of a pass: conv1_1+conv1_2 fused .. conv_cls.4+tail)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-        "traffic": None,
+        "traffic": traffic, "traffic_source": traffic_src,
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
         "algorithmic_gflop_per_page": conv_flops / 1e9 / max(B * args.steps, 1),
         "recogniser_convs": {"achieved": rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0, "launches": rec_launches,
