@@ -232,3 +232,32 @@ def test_hip_path_against_committed_golden(reader):
     heat2 = torch.from_numpy(np.stack([gb["text"], gb["link"]], -1)[None].astype(np.float32)).cuda()
     hori, free, polys = reader.boxes_from_heatmap(heat2, 1.0)
     assert np.array_equal(np.array(polys[0], dtype=np.int32), gb["polys"]) and np.array_equal(np.array(hori[0], dtype=np.int64).reshape(-1, 4), gb["hori"])
+
+
+def test_full_size_batch_properties(reader):
+    """BASELINE.json's measured configuration (64 pages of 1280x960; 8 distinct pages tiled like bench.py), checked through
+    size-independent properties: copies of a page give identical results, a page's result does not depend on the batch it
+    travels in, the detector's pass schedule ([56, 8] auto vs uniform passes of 8) does not change a single heat-map bit, and
+    a second run reproduces the first."""
+    import bb_ocr_amd
+    from bb_ocr_amd import synth, weights
+
+    uniq = [synth.page(1000 + i)[0] for i in range(8)]
+    assert uniq[0].shape == (960, 1280, 3)
+    rgb = torch.from_numpy(np.stack([uniq[i % 8] for i in range(64)])).cuda()
+    out = reader.readtext_device(rgb)
+    assert len(out) == 64 and all(len(p) > 10 for p in out)
+    for i in range(8, 64):
+        assert out[i] == out[i % 8], f"copy {i} of page {i % 8} differs"
+    assert reader.readtext_device(rgb) == out                                   # run-to-run
+    for i in range(8):
+        assert reader.readtext_device(rgb[i:i + 1])[0] == out[i], f"page {i}: batch of 1 differs from batch of 64"
+    assert reader.readtext_device(rgb[5:30]) == out[5:30]                        # 25 pages: schedule [17, 8]
+    heat, ratio = reader.heatmap_device(rgb)
+    other = bb_ocr_amd.Reader(["en"], weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), det_sub_batch=8)
+    heat8, ratio8 = other.heatmap_device(rgb)
+    assert ratio == ratio8 and torch.equal(heat, heat8)
+    # every word the renderer drew is found exactly once on every page (boxes are word-level for this detector)
+    words = [len(synth.page(1000 + i)[1]) for i in range(8)]
+    polys = reader.boxes_from_heatmap(heat, ratio)[2]
+    assert [len(p) for p in polys[:8]] == words
