@@ -1,0 +1,69 @@
+"""Caller-side batching for the reference's extractor.
+
+``pipeline_demo/extractor/enhanced_extractor.py`` runs OCR page by page: the loop at :680-688 calls
+``extract_text_with_ocr`` per image, which (after the optional crop logic) applies the down-scaling rule of :486-512 and then
+``reader.readtext(path, paragraph=False, batch_size=1, workers=0)`` (:520), joins ``result[1]`` with spaces (:521) and maps any
+exception to the empty string (:529-531).  ``extract_texts`` does the same for ALL pages of a book (or of many books) with ONE
+``readtext_batched`` call per page shape, so the backend sees 64-page batches instead of single pages.
+
+Only the OCR step is batched; cropping / LLM steps of the extractor stay where they are.  The down-scaling rule is restated
+exactly, including its JPEG round trip (the reference writes the thumbnail as JPEG quality 90/95 and lets easyocr decode it).
+"""
+from __future__ import annotations
+
+import io
+import os
+
+import numpy as np
+
+
+def ocr_input_image(image_path, image_index=None):
+    """The pixels ``extract_text_with_ocr`` hands to easyocr for ``image_path`` (enhanced_extractor.py:486-512): pages whose
+    longer side exceeds 1600 px (cover, ``image_index`` None or 0) / 2400 px (other pages) are ``Image.thumbnail``-ed to that
+    size in RGB and re-encoded as JPEG quality 90 / 95; everything else is read as is.  Returns what ``reformat_input`` would
+    produce for the file easyocr is given: (RGB uint8 [H,W,3], gray uint8 [H,W])."""
+    from PIL import Image
+
+    from .reader import reformat_input
+
+    cover = image_index is None or image_index == 0
+    max_dim = 1600 if cover else 2400
+    try:
+        img = Image.open(image_path)
+        if max(img.size) > max_dim:
+            img = img.convert("RGB")
+            img.thumbnail((max_dim, max_dim))
+            buf = io.BytesIO()
+            img.save(buf, format="JPEG", quality=(90 if cover else 95))
+            pil = Image.open(io.BytesIO(buf.getvalue()))          # what easyocr's loader sees: a JPEG file on disk
+            return np.ascontiguousarray(pil.convert("RGB")), np.ascontiguousarray(pil.convert("L"))
+    except Exception:
+        pass                                                      # :511-514: any failure falls back to the original file
+    return reformat_input(os.fspath(image_path))
+
+
+def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, **readtext_kw):
+    """``{index: text}`` for every index of ``ocr_image_indices`` (default: all pages), text = ``" ".join(r[1] for r in results)``
+    exactly as :521; a page whose OCR fails gets ``""`` like :529-531.  Pages of equal (down-scaled) shape travel in one device
+    batch of at most ``max_batch`` pages."""
+    if ocr_image_indices is None:
+        ocr_image_indices = range(len(image_paths))
+    idxs = [i for i in ocr_image_indices if 0 <= i < len(image_paths)]
+    texts = {i: "" for i in idxs}
+    by_shape = {}
+    for i in idxs:
+        try:
+            rgb, gray = ocr_input_image(image_paths[i], i)
+        except Exception:
+            continue
+        by_shape.setdefault(rgb.shape, []).append((i, rgb, gray))
+    for _, items in by_shape.items():
+        for s in range(0, len(items), max_batch):
+            part = items[s:s + max_batch]
+            try:
+                res = reader.readtext_arrays(np.stack([p[1] for p in part]), np.stack([p[2] for p in part]), **readtext_kw)
+            except Exception:
+                continue
+            for (i, _, _), r in zip(part, res):
+                texts[i] = " ".join(item[1] for item in r)
+    return texts

@@ -148,7 +148,10 @@ class Reader:
         return p
 
     def _to_dev(self, arr):
-        t = self._torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        arr = np.ascontiguousarray(arr)
+        if not arr.flags.writeable:          # e.g. a view of a PIL image: torch wants a writable source
+            arr = arr.copy()
+        t = self._torch.from_numpy(arr).to(self.device)
         self._torch.cuda.current_stream(self.device_index).synchronize()
         return t
 
@@ -244,6 +247,13 @@ class Reader:
             for i, r in zip(idxs, self.readtext_device(rgb, gray, **kw)):
                 out[i] = r
         return out
+
+    def readtext_arrays(self, rgb, gray=None, **kw):
+        """Host arrays ``uint8 [B,H,W,3]`` (+ optional ``[B,H,W]`` gray planes, else derived on device) -> per-page results."""
+        rgb = np.asarray(rgb)
+        if rgb.dtype != np.uint8 or rgb.ndim != 4 or rgb.shape[3] != 3:
+            raise ValueError("readtext_arrays expects uint8 [B,H,W,3]")
+        return self.readtext_device(self._to_dev(rgb), self._to_dev(np.asarray(gray)) if gray is not None else None, **kw)
 
     def detect(self, img, min_size=20, text_threshold=0.7, low_text=0.4, link_threshold=0.4, canvas_size=2560, mag_ratio=1.0,
                slope_ths=0.1, ycenter_ths=0.5, height_ths=0.5, width_ths=0.5, add_margin=0.1, reformat=True, **_ignored):

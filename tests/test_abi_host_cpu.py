@@ -226,3 +226,75 @@ def test_shard_range_partitions_exactly():
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
     assert dist.shard_range(512, 3, 8) == (192, 256)
+
+
+def test_tesseract_shim_reading_order_and_install():
+    """a12: rows by vertical overlap, left to right, newline-joined; the module registers under the name scripts import."""
+    import sys
+
+    from bb_ocr_amd import tesseract_shim as ts
+
+    def box(x0, y0, x1, y1):
+        return [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+
+    res = [(box(200, 12, 260, 30), "world", 0.9), (box(10, 10, 80, 32), "hello", 0.9), (box(12, 60, 90, 80), "second", 0.8),
+           (box(100, 58, 150, 82), "row", 0.7), (box(10, 120, 40, 140), "x", 0.5)]
+    rows = ts.lines_from_results(res)
+    assert [[it[1] for it in r] for r in rows] == [["hello", "world"], ["second", "row"], ["x"]]
+
+    class FakeReader:
+        def readtext(self, image, **kw):
+            return res
+
+    assert ts.image_to_string(np.zeros((8, 8, 3), np.uint8), reader=FakeReader()) == "hello world\nsecond row\nx\n"
+    prev = sys.modules.get("pytesseract")
+    try:
+        m = ts.install(reader=FakeReader())
+        import pytesseract
+
+        assert pytesseract is m and pytesseract.image_to_string(np.zeros((8, 8, 3), np.uint8)) == "hello world\nsecond row\nx\n"
+    finally:
+        ts.uninstall()
+        ts.set_reader(None)
+    assert sys.modules.get("pytesseract") is prev
+
+
+def test_extractor_downscale_rule_and_batching(tmp_path):
+    """f3: the reference's OCR-input rule (enhanced_extractor.py:486-512) and the batched text assembly (:521, :529-531)."""
+    from PIL import Image
+
+    from bb_ocr_amd import extractor_batch as eb
+
+    rng = np.random.default_rng(0)
+    big = tmp_path / "big.png"
+    small = tmp_path / "small.png"
+    Image.fromarray(rng.integers(0, 256, (1000, 3000, 3), dtype=np.uint8)).save(big)
+    Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)).save(small)
+    rgb0, g0 = eb.ocr_input_image(big, 0)          # cover: <= 1600
+    rgb1, g1 = eb.ocr_input_image(big, 3)          # other pages: <= 2400
+    assert rgb0.shape == (533, 1600, 3) and g0.shape == (533, 1600)
+    assert rgb1.shape == (800, 2400, 3)
+    rs, gs = eb.ocr_input_image(small, 0)
+    assert rs.shape == (300, 400, 3) and np.array_equal(rs, np.asarray(Image.open(small).convert("RGB")))
+    # the reference's own sequence for the cover page
+    import io
+    im = Image.open(big).convert("RGB")
+    im.thumbnail((1600, 1600))
+    buf = io.BytesIO()
+    im.save(buf, format="JPEG", quality=90)
+    assert np.array_equal(rgb0, np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
+
+    class FakeReader:
+        def __init__(self):
+            self.batches = []
+
+        def readtext_arrays(self, rgb, gray=None, **kw):
+            self.batches.append(rgb.shape)
+            if rgb.shape[1] == 300:
+                raise RuntimeError("boom")             # a failing batch maps to empty text, like :529-531
+            return [[(None, f"w{rgb.shape[2]}", 0.9), (None, "x", 0.5)] for _ in range(rgb.shape[0])]
+
+    fr = FakeReader()
+    texts = eb.extract_texts(fr, [big, small, big, tmp_path / "missing.png"], [1, 2, 0, 3, 7])
+    assert texts == {1: "", 2: "w2400 x", 0: "w1600 x", 3: ""}
+    assert sorted(fr.batches) == sorted([(1, 300, 400, 3), (1, 800, 2400, 3), (1, 533, 1600, 3)])

@@ -261,3 +261,23 @@ def test_full_size_batch_properties(reader):
     words = [len(synth.page(1000 + i)[1]) for i in range(8)]
     polys = reader.boxes_from_heatmap(heat, ratio)[2]
     assert [len(p) for p in polys[:8]] == words
+
+
+def test_extractor_batching_and_tesseract_shim(reader, tmp_path):
+    """f3 / a12 on the GPU: batched extraction returns exactly the per-page ``" ".join`` of ``readtext``; the pytesseract shim
+    returns one line of text per rendered text line."""
+    from PIL import Image
+
+    from bb_ocr_amd import extractor_batch as eb, synth, tesseract_shim as ts
+
+    paths = []
+    for i in range(3):
+        img, _ = synth.page(300 + i, width=640, height=384, lines=5, margin=24)
+        p = tmp_path / f"p{i}.png"
+        Image.fromarray(img).save(p)
+        paths.append(p)
+    texts = eb.extract_texts(reader, paths)
+    for i, p in enumerate(paths):
+        assert texts[i] == " ".join(r[1] for r in reader.readtext(str(p)))
+    s = ts.image_to_string(Image.open(paths[0]), reader=reader)
+    assert s.endswith("\n") and len(s.strip().split("\n")) == 5
