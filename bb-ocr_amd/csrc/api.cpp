@@ -79,6 +79,7 @@ struct Act {   // bf16 NHWC activation
 struct bbocr_ctx {
     bbocr_config cfg{};
     hipStream_t stream = nullptr;
+    DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
     hipStream_t cur = nullptr;                // stream the layer helpers launch on (stream, or a recogniser side stream)
     hipStream_t rstream[4] = {nullptr, nullptr, nullptr, nullptr};   // recogniser conv stacks of different width buckets run side by side
     hipEvent_t rjoin[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1060,6 +1061,179 @@ static bbocr_result* export_result(int B, const std::vector<BoxJob>& jobs, const
     return r;
 }
 
+// ------------------------------------------------------------------------------------------------ pre-processing chain (f2)
+// Host-side constants of the chain, computed exactly like oracle/preprocess.py (float32 where the C sources use float).
+struct CubicAxis { std::vector<int> first; std::vector<short> coef; };
+static CubicAxis cubic_axis(int dst, int src) {   // imgproc resize.cpp: fx in float, cvFloor, interpolateCubic (A = -0.75), cvRound(c * 2048)
+    CubicAxis a;
+    a.first.resize(dst);
+    a.coef.resize((size_t)dst * 4);
+    const double scale = (double)src / (double)dst;
+    const float A = -0.75f;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)std::floor(f);
+        f = f - (float)s;
+        float c[4];
+        const float x = f;
+        c[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+        c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+        c[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        a.first[d] = s - 1;
+        for (int k = 0; k < 4; ++k) {
+            long v = std::lrint((double)c[k] * 2048.0);        // cvRound: half to even
+            a.coef[(size_t)d * 4 + k] = (short)std::max<long>(-32768, std::min<long>(32767, v));
+        }
+    }
+    return a;
+}
+static void gaussian_taps3(double sigma, int k[3]) {   // getGaussianKernelBitExact -> 8.8 fixed point, error diffusion (sum 256)
+    double v[3], tot = 0;
+    for (int i = 0; i < 3; ++i) { v[i] = std::exp(-((double)(i - 1) * (i - 1)) / (2.0 * sigma * sigma)); tot += v[i]; }
+    double err = 0;
+    for (int i = 0; i < 3; ++i) {
+        const double t = v[i] / tot * 256.0;
+        const int r = (int)std::floor(t + err + 0.5);
+        err += t - r;
+        k[i] = r;
+    }
+}
+static void pil_blend_lut(int in1, float alpha, uint8_t lut[256]) {   // libImaging/Blend.c with a constant first image
+    for (int v = 0; v < 256; ++v) {
+        const float t = (float)in1 + alpha * (float)(v - in1);
+        if (alpha >= 0.f && alpha <= 1.f) lut[v] = (uint8_t)t;
+        else lut[v] = t <= 0.f ? 0 : (t >= 255.f ? 255 : (uint8_t)t);
+    }
+}
+static float pil_box_radius(float radius, int passes) {   // libImaging/BoxBlur.c::_gaussian_blur_radius
+    const float sigma2 = radius * radius / (float)passes;
+    const float L = (float)std::sqrt(12.0 * (double)sigma2 + 1.0);
+    const float l = (float)std::floor(((double)L - 1.0) / 2.0);
+    float a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a = a / (6 * (sigma2 - (l + 1) * (l + 1)));
+    return l + a;
+}
+
+static void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw) {
+    const CubicAxis ax = cubic_axis(dw, W), ay = cubic_axis(dh, H);
+    const size_t bytes = (size_t)dw * 4 + (size_t)dw * 8 + (size_t)dh * 4 + (size_t)dh * 8;
+    c->pp_tab.ensure(bytes);
+    unsigned char* t = (unsigned char*)c->pp_tab.p;
+    int* x0 = (int*)t;                         t += (size_t)dw * 4;
+    int* y0 = (int*)t;                         t += (size_t)dh * 4;
+    short* cx = (short*)t;                     t += (size_t)dw * 8;
+    short* cy = (short*)t;
+    HIPCHK(hipMemcpyAsync(x0, ax.first.data(), (size_t)dw * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(y0, ay.first.data(), (size_t)dh * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(cx, ax.coef.data(), (size_t)dw * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(cy, ay.coef.data(), (size_t)dh * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, cx, y0, cy, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // the host tables must outlive the copies
+}
+// GaussianBlur 3x3; returns the sum of the output pixels (for the following Contrast step)
+static unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma) {
+    int k[3];
+    gaussian_taps3(sigma, k);
+    c->pp_tab.ensure(64);
+    HIPCHK(hipMemsetAsync(c->pp_tab.p, 0, 8, c->stream));
+    HIPCHK(launch_pp_gauss3(src, H, W, dst, k[0], k[1], k[2], (unsigned long long*)c->pp_tab.p, c->stream));
+    unsigned long long sum = 0;
+    HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return sum;
+}
+// CLAHE of lut[src] (lut = pointwise steps folded in front of it; identity if null)
+static void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit) {
+    const int tx = 8, ty = 8;
+    // clahe.cpp pads BOTH axes by tiles - (size % tiles) as soon as ONE of them is not a multiple of the grid -- a whole extra
+    // 8 rows / columns on the axis that did divide (upstream quirk, restated as is)
+    const bool pad = (H % ty) || (W % tx);
+    const int EH = pad ? H + (ty - H % ty) : H, EW = pad ? W + (tx - W % tx) : W;
+    if (EH - H >= H || EW - W >= W) fail(BBOCR_ERR_ARG, "image smaller than the CLAHE tile grid");
+    const int th = EH / ty, tw = EW / tx;
+    c->pp_tab.ensure(256 + (size_t)tx * ty * 256 * 4 + (size_t)tx * ty * 256);
+    uint8_t* d_lut = (uint8_t*)c->pp_tab.p;
+    unsigned int* d_hist = (unsigned int*)((unsigned char*)c->pp_tab.p + 256);
+    uint8_t* d_tl = (uint8_t*)c->pp_tab.p + 256 + (size_t)tx * ty * 256 * 4;
+    uint8_t ident[256];
+    for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+    HIPCHK(hipMemcpyAsync(d_lut, lut_host ? lut_host : ident, 256, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)tx * ty * 256 * 4, c->stream));
+    HIPCHK(launch_pp_clahe_hist(src, H, W, d_lut, tw, th, tx, ty, d_hist, c->stream));
+    std::vector<unsigned int> hist((size_t)tx * ty * 256);
+    HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // imgproc clahe.cpp: clip + redistribute, LUT = cvRound(cumsum * 255 / tile_area) in float
+    const int area = th * tw;
+    const float lut_scale = 255.0f / (float)area;
+    int clip = 0;
+    if (clip_limit > 0) clip = std::max((int)(clip_limit * area / 256), 1);
+    std::vector<uint8_t> tl((size_t)tx * ty * 256);
+    for (int t = 0; t < tx * ty; ++t) {
+        long long h[256];
+        for (int i = 0; i < 256; ++i) h[i] = hist[(size_t)t * 256 + i];
+        if (clip > 0) {
+            long long clipped = 0;
+            for (int i = 0; i < 256; ++i) if (h[i] > clip) { clipped += h[i] - clip; h[i] = clip; }
+            const long long batch = clipped / 256;
+            long long residual = clipped - batch * 256;
+            for (int i = 0; i < 256; ++i) h[i] += batch;
+            if (residual) {
+                const int step = std::max((int)(256 / residual), 1);
+                for (int i = 0; i < 256 && residual > 0; i += step, --residual) h[i] += 1;
+            }
+        }
+        long long sum = 0;
+        for (int i = 0; i < 256; ++i) {
+            sum += h[i];
+            const long v = std::lrintf((float)sum * lut_scale);
+            tl[(size_t)t * 256 + i] = (uint8_t)std::max<long>(0, std::min<long>(255, v));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d_tl, tl.data(), tl.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_pp_clahe_apply(src, H, W, d_lut, d_tl, tw, th, tx, ty, dst, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+}
+// PIL UnsharpMask on src -> dst; tmp1/tmp2: two scratch planes of the same size
+static void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent,
+                       int threshold) {
+    const float fr = pil_box_radius(radius, 3);
+    const int r = (int)fr;
+    const unsigned int ww = (unsigned int)((float)(1 << 24) / (fr * 2.f + 1.f));
+    const unsigned int fw = ((1u << 24) - (unsigned int)(r * 2 + 1) * ww) / 2;
+    const uint8_t* cur = src;
+    uint8_t* bufs[2] = {tmp1, tmp2};
+    int w = 0;
+    for (int pass = 0; pass < 6; ++pass) {
+        HIPCHK(launch_pp_box_pass(cur, bufs[w], H, W, pass >= 3, r, ww, fw, c->stream));
+        cur = bufs[w];
+        w ^= 1;
+    }
+    HIPCHK(launch_pp_unsharp(src, cur, dst, (size_t)H * W, percent, threshold, c->stream));
+}
+
+static void preprocess_book_cover_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, uint8_t* out, int dh, int dw) {
+    const size_t n = (size_t)dh * dw;
+    c->pp_gray.ensure((size_t)H * W);
+    c->pp_a.ensure(n);
+    c->pp_b.ensure(n);
+    c->pp_c.ensure(n);
+    uint8_t *g = (uint8_t*)c->pp_gray.p, *a = (uint8_t*)c->pp_a.p, *b = (uint8_t*)c->pp_b.p, *cc = (uint8_t*)c->pp_c.p;
+    HIPCHK(launch_gray(bgr, g, (size_t)H * W, c->stream));             // channels as given: B 1868, G 9617, R 4899 for cv2.imread's BGR
+    pp_resize(c, g, H, W, a, dh, dw);
+    const unsigned long long sum = pp_gauss(c, a, dh, dw, b, 3.0);
+    // ImageEnhance.Contrast(1.9) then Brightness(1.2): two pointwise maps, folded into one LUT in front of CLAHE
+    const int mean = (int)((double)sum / (double)n + 0.5);
+    uint8_t l1[256], l2[256], lut[256];
+    pil_blend_lut(mean, 1.9f, l1);
+    pil_blend_lut(0, 1.2f, l2);
+    for (int i = 0; i < 256; ++i) lut[i] = l2[l1[i]];
+    pp_clahe(c, b, dh, dw, lut, a, 2.5);
+    pp_unsharp(c, a, dh, dw, out, b, cc, 1.0f, 30, 3);
+    HIPCHK(hipStreamSynchronize(c->stream));
+}
+
 template <typename F> static int guarded(bbocr_ctx* ctx, F&& f) {
     if (!ctx) return BBOCR_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1067,6 +1241,10 @@ template <typename F> static int guarded(bbocr_ctx* ctx, F&& f) {
         hipError_t e = hipSetDevice(ctx->cfg.device);
         if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
         ctx->cur = ctx->stream;
+        // the library runs on its own non-blocking streams: what the caller queued on the default stream (torch's) -- fills of
+        // output buffers, input copies -- must be complete before our kernels touch the same memory
+        e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("default stream: ") + hipGetErrorString(e));
         f();
         return BBOCR_OK;
     } catch (const StatusError& se) {
@@ -1148,7 +1326,7 @@ void bbocr_destroy(bbocr_ctx* c) {
     DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
                       &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
                       &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
-                      &c->seq_tables};
+                      &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab};
     for (DevBuf* b : bufs) b->release();
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1284,6 +1462,61 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
         prof_collect(ctx);
         *out = export_result(B, jobs, off);
         ctx->times[7] = (float)ms_since(t_all);
+    });
+}
+
+int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w) {
+    return guarded(ctx, [&] {
+        if (H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad image shape");
+        const int dh = (int)(H * 1.5), dw = (int)(W * 1.5);
+        if (out_h) *out_h = dh;
+        if (out_w) *out_w = dw;
+        if (!dev_out) return;
+        if (!dev_bgr) fail(BBOCR_ERR_ARG, "null device pointer");
+        if (dh < 16 || dw < 16) fail(BBOCR_ERR_ARG, "image too small for the 8x8 CLAHE tile grid");
+        preprocess_book_cover_impl(ctx, dev_bgr, H, W, dev_out, dh, dw);
+    });
+}
+
+int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src, int H, int W, uint8_t* dev_dst, int dh, int dw, double param) {
+    return guarded(ctx, [&] {
+        if (!dev_src || !dev_dst || H <= 0 || W <= 0 || dh <= 0 || dw <= 0) fail(BBOCR_ERR_ARG, "bad arguments");
+        if (stage != 0 && (dh != H || dw != W)) fail(BBOCR_ERR_ARG, "only stage 0 changes the size");
+        const size_t n = (size_t)H * W;
+        if (stage == 0) {
+            pp_resize(ctx, dev_src, H, W, dev_dst, dh, dw);
+        } else if (stage == 1) {
+            (void)pp_gauss(ctx, dev_src, H, W, dev_dst, param);
+        } else if (stage == 2 || stage == 3) {
+            // pointwise PIL enhancers: the chain folds them into CLAHE's input LUT; stand-alone they are one lookup pass
+            uint8_t lut[256];
+            if (stage == 2) {
+                ctx->pp_a.ensure(n);
+                ctx->pp_tab.ensure(512);
+                HIPCHK(hipMemsetAsync(ctx->pp_tab.p, 0, 8, ctx->stream));
+                // mean of the input: the 3x3 smoothing kernel with taps (0, 256, 0) is the identity and sums its output
+                HIPCHK(launch_pp_gauss3(dev_src, H, W, (uint8_t*)ctx->pp_a.p, 0, 256, 0, (unsigned long long*)ctx->pp_tab.p, ctx->stream));
+                unsigned long long sm = 0;
+                HIPCHK(hipMemcpyAsync(&sm, ctx->pp_tab.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                pil_blend_lut((int)((double)sm / (double)n + 0.5), (float)param, lut);
+            } else {
+                pil_blend_lut(0, (float)param, lut);
+            }
+            ctx->pp_tab.ensure(512);
+            HIPCHK(hipMemcpyAsync((unsigned char*)ctx->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(launch_pp_lut(dev_src, dev_dst, (const uint8_t*)ctx->pp_tab.p + 256, n, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        } else if (stage == 4) {
+            pp_clahe(ctx, dev_src, H, W, nullptr, dev_dst, param);
+        } else if (stage == 5) {
+            ctx->pp_b.ensure(n);
+            ctx->pp_c.ensure(n);
+            pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, (float)param, 30, 3);
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        } else {
+            fail(BBOCR_ERR_ARG, "unknown pre-processing stage");
+        }
     });
 }
 

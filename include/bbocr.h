@@ -34,6 +34,9 @@ enum bbocr_status {
     BBOCR_ERR_INTERNAL = -6
 };
 
+/* Streams: every context owns non-blocking HIP streams.  On entry each call waits for the legacy default stream (where torch
+ * queues its copies and fills by default); device buffers produced on OTHER streams must be complete before they are passed in.
+ * Every call returns with its own work finished (results are host-visible / device buffers final). */
 typedef struct bbocr_config {
     int device;         /* HIP device ordinal */
     int det_sub_batch;  /* pages per detector pass; 0 = auto (<= 64 pages / 96 GB of activations, short last pass) */
@@ -162,6 +165,17 @@ int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, in
  * is imgW (in box order); returns their count in *n_out.  contrast != 0 applies adjust_contrast_grey first. */
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free,
                    int imgW, float contrast, uint16_t* dev_out, int* n_out);
+
+/* ---- OCR pre-processing chain of the reference ----
+ * pipeline_demo/ocr_testing/preprocessing/image_preprocessor.py::preprocess_for_book_cover (:147-160) on ONE decoded page:
+ * dev_bgr uint8 [H,W,3] in cv2.imread's channel order -> dev_out uint8 [int(H*1.5), int(W*1.5)] (gray): BGR2GRAY, x1.5
+ * INTER_CUBIC, GaussianBlur 3x3 sigma 3, PIL Contrast 1.9, PIL Brightness 1.2, CLAHE (clip 2.5, 8x8 tiles),
+ * PIL UnsharpMask(radius 1, 30 %, threshold 3).  out_h / out_w receive the output size (pass dev_out = NULL to query it). */
+int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w);
+/* the chain's stages one by one on a gray plane (parity tests): stage 0 = resize cubic to (dh, dw), 1 = GaussianBlur 3x3
+ * sigma `param`, 2 = PIL Contrast `param`, 3 = PIL Brightness `param`, 4 = CLAHE clip `param` 8x8, 5 = PIL UnsharpMask
+ * (radius `param`, 30 %, threshold 3).  Stages 1-5 keep the size (dh = H, dw = W). */
+int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src, int H, int W, uint8_t* dev_dst, int dh, int dw, double param);
 
 #ifdef __cplusplus
 }

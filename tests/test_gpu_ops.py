@@ -114,6 +114,7 @@ def test_resize_u8_bit_exact(reader):
         src = rng.integers(0, 256, (2, sh, sw, c), dtype=np.uint8)
         d = torch.from_numpy(src).cuda()
         out = torch.zeros((2, dh, dw, c), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the library on its own non-blocking one
         reader._check(reader._lib.bbocr_op_resize_u8(reader._h, C.c_void_p(d.data_ptr()), 2, sh, sw, c, C.c_void_p(out.data_ptr()), dh, dw))
         got = out.cpu().numpy()
         for n in range(2):
@@ -142,3 +143,40 @@ def test_ctc_matches_oracle(reader):
         assert text == ref[i][0]
         assert conf[i] == pytest.approx(float(ref[i][1]), rel=2e-5, abs=1e-12)
     assert off[1] - off[0] == 0 and conf[0] == 0.0
+
+
+def test_preprocess_chain_bit_exact_vs_oracle(reader):
+    """f2: every stage of preprocess_for_book_cover and the whole chain, bit for bit against oracle/preprocess.py (whose PIL
+    stages are pinned against Pillow in the CPU suite)."""
+    import ctypes as C
+
+    from bb_ocr_amd import preprocess as dev_pp, synth
+    from oracle import preprocess as pp
+
+    rng = np.random.default_rng(11)
+
+    def stage(k, a, param, dh=None, dw=None):
+        src = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        dh, dw = dh or a.shape[0], dw or a.shape[1]
+        dst = torch.empty((dh, dw), dtype=torch.uint8, device="cuda")
+        reader._check(reader._lib.bbocr_op_preprocess_stage(reader._h, k, C.c_void_p(src.data_ptr()), a.shape[0], a.shape[1],
+                                                            C.c_void_p(dst.data_ptr()), dh, dw, float(param)))
+        return dst.cpu().numpy()
+
+    for shape in ((67, 91), (128, 200), (301, 257), (184, 316), (90, 128)):     # incl. one axis only a multiple of the CLAHE grid
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = rng.normal(190, 35, shape).clip(0, 255).astype(np.uint8)
+        for img in (a, b):
+            dh, dw = int(shape[0] * 1.5), int(shape[1] * 1.5)
+            assert np.array_equal(stage(0, img, 0, dh, dw), pp.resize_cubic_u8(img, dw, dh))
+            assert np.array_equal(stage(1, img, 3.0), pp.gaussian_blur3_u8(img, 3.0))
+            assert np.array_equal(stage(2, img, 1.9), pp.pil_contrast_L(img, 1.9))
+            assert np.array_equal(stage(3, img, 1.2), pp.pil_brightness_L(img, 1.2))
+            assert np.array_equal(stage(4, img, 2.5), pp.clahe_u8(img, 2.5, (8, 8)))
+            assert np.array_equal(stage(5, img, 1.0), pp.pil_unsharp_L(img, 1.0, 30, 3))
+    # the whole chain on a rendered page (BGR) and on noise
+    page = synth.page(77, width=640, height=400, lines=8, margin=24)[0][:, :, ::-1]
+    for bgr in (np.ascontiguousarray(page), rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)):
+        got, path, steps = dev_pp.preprocess_for_book_cover(bgr, reader=reader)
+        assert path is None and steps == pp.STEPS
+        assert np.array_equal(got, pp.preprocess_for_book_cover(bgr))

@@ -123,6 +123,7 @@ def _crops_case(reader, grey, hori, free, contrast):
     for mw in widths:
         want = [recog.align_collate_one(c, 64, mw, adjust_contrast=contrast) for c, m in items if m == mw]
         out = torch.zeros((len(want), 64, mw), dtype=torch.bfloat16, device="cuda")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the library on its own non-blocking one
         n_out = C.c_int()
         reader._check(reader._lib.bbocr_op_crops(reader._h, C.c_void_p(d.data_ptr()), H, W, harr, len(hori), farr, len(free), mw, float(contrast),
                                                  C.c_void_p(out.data_ptr()), C.byref(n_out)))
@@ -156,6 +157,7 @@ def test_crnn_logits_within_tolerance(reader, oracle_reader):
         ref = oracle_reader._logits(xb.float().numpy())
         T = W // 4 - 1
         out = torch.zeros((n, T, 112), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the library on its own non-blocking one
         reader._check(reader._lib.bbocr_crnn_logits(reader._h, C.c_void_p(xb[:, 0].contiguous().cuda().data_ptr()), n, W, C.c_void_p(out.data_ptr())))
         got = out.cpu().numpy()[:, :, :97]
         rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
@@ -224,6 +226,7 @@ def test_hip_path_against_committed_golden(reader):
     assert np.array_equal(np.array([b for b, _, _ in out], dtype=np.int64), g["boxes"])
     x = torch.from_numpy(g["crnn_in"].astype(np.float32)).to(torch.bfloat16)
     lg = torch.zeros((1, 31, 112), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # the fill runs on torch's stream, the library on its own non-blocking one
     reader._check(reader._lib.bbocr_crnn_logits(reader._h, C.c_void_p(x[:, 0].contiguous().cuda().data_ptr()), 1, 128, C.c_void_p(lg.data_ptr())))
     ref = g["crnn_logits"]
     rel = np.linalg.norm(lg.cpu().numpy()[:, :, :97] - ref) / np.linalg.norm(ref)

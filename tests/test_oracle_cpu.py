@@ -171,3 +171,55 @@ def test_designed_detector_finds_every_word(oracle_reader):
     st, sl, ratio = oracle_reader.heatmap(img)
     boxes, _, _ = obox.get_det_boxes_core(st, sl)
     assert len(boxes) == len(words)
+
+
+def test_preprocess_pil_stages_pinned_against_pillow():
+    """f2: the three PIL stages of preprocess_for_book_cover restated in oracle/preprocess.py are checked against Pillow itself
+    (ImageEnhance.Contrast / Brightness, ImageFilter.GaussianBlur / UnsharpMask) -- real parity, not self-consistency."""
+    from PIL import Image, ImageEnhance, ImageFilter
+
+    from oracle import preprocess as pp
+
+    rng = np.random.default_rng(3)
+    for shape in ((37, 53), (120, 200), (5, 3)):
+        for kind in range(3):
+            if kind == 0:
+                a = rng.integers(0, 256, shape, dtype=np.uint8)
+            elif kind == 1:
+                a = rng.normal(200, 30, shape).clip(0, 255).astype(np.uint8)
+            else:
+                a = np.full(shape, 230, np.uint8)
+                a[: shape[0] // 2, : shape[1] // 2] = 20
+            im = Image.fromarray(a)
+            for f in (1.9, 0.5, 1.0, 3.0):
+                assert np.array_equal(np.asarray(ImageEnhance.Contrast(im).enhance(f)), pp.pil_contrast_L(a, f))
+            for f in (1.2, 0.7, 2.5):
+                assert np.array_equal(np.asarray(ImageEnhance.Brightness(im).enhance(f)), pp.pil_brightness_L(a, f))
+            for r in (1.0, 2.0, 0.5):
+                assert np.array_equal(np.asarray(im.filter(ImageFilter.GaussianBlur(r))), pp.pil_gaussian_blur_L(a, r))
+            for r, p, t in ((1.0, 30, 3), (2.0, 150, 0), (1.0, 80, 10)):
+                assert np.array_equal(np.asarray(im.filter(ImageFilter.UnsharpMask(radius=r, percent=p, threshold=t))), pp.pil_unsharp_L(a, r, p, t))
+
+
+def test_preprocess_cv_stages_known_answers():
+    """f2: properties the OpenCV stages must have whatever the build: constants are fixed points, the blur taps are the
+    published 8.8 kernel, cubic resize reproduces linear ramps away from the borders, CLAHE of a flat tile stays in range."""
+    from oracle import preprocess as pp
+
+    assert pp.gaussian_kernel3_fixed(3.0) == [84, 88, 84] and sum(pp.gaussian_kernel3_fixed(0.8)) == 256
+    flat = np.full((40, 56), 77, np.uint8)
+    assert np.array_equal(pp.gaussian_blur3_u8(flat, 3.0), flat)
+    assert np.array_equal(pp.resize_scale_u8(flat, 1.5), np.full((60, 84), 77, np.uint8))
+    assert np.array_equal(pp.bgr2gray(np.stack([flat, flat, flat], -1)), flat)          # 1868 + 9617 + 4899 = 2^14
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (30, 1))                       # slope 2 per source pixel
+    up = pp.resize_scale_u8(ramp, 1.5).astype(np.int64)
+    d = np.diff(up[10, 6:-6])
+    assert d.min() >= 1 and d.max() <= 2 and abs(float(d.mean()) - 4.0 / 3.0) < 0.05   # cubic reproduces a linear ramp
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (67, 91), dtype=np.uint8)                                # not a multiple of the 8x8 grid
+    out = pp.clahe_u8(img, 2.5, (8, 8))
+    assert out.shape == img.shape and out.dtype == np.uint8
+    # monotone per tile LUTs and bilinear blending keep the local order of well separated grey levels
+    assert out[img > 200].mean() > out[img < 50].mean() + 50
+    full = pp.preprocess_for_book_cover(rng.integers(0, 256, (41, 62, 3), dtype=np.uint8))
+    assert full.shape == (61, 93) and full.dtype == np.uint8
