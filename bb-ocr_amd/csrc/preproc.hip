@@ -69,6 +69,47 @@ __global__ void __launch_bounds__(256) pp_gauss3_kernel(const uint8_t* __restric
     }
 }
 
+// ---- the same, four pixels per thread (W % 4 == 0): three dword row loads + the two columns next to them
+__global__ void __launch_bounds__(256) pp_gauss3_x4_kernel(const uint8_t* __restrict__ src, int H, int W, uint8_t* __restrict__ dst, int k0, int k1, int k2,
+                                                            unsigned long long* __restrict__ sum) {
+    const int W4 = W >> 2;
+    const size_t total = (size_t)H * W4;
+    unsigned long long local = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W4), x = (int)(i - (size_t)y * W4) << 2;
+        const int xm = x > 0 ? x - 1 : (W > 1 ? 1 : 0), xp = x + 4 < W ? x + 4 : (W > 1 ? W - 2 : 0);
+        const int ym = y > 0 ? y - 1 : (H > 1 ? 1 : 0), yp = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);
+        int hrow[3][4];
+        const int ys[3] = {ym, y, yp};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint8_t* row = src + (size_t)ys[r] * W;
+            const unsigned int c = *(const unsigned int*)(row + x);
+            const int p[6] = {row[xm], (int)(c & 255u), (int)((c >> 8) & 255u), (int)((c >> 16) & 255u), (int)(c >> 24), row[xp]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hrow[r][k] = k0 * p[k] + k1 * p[k + 1] + k2 * p[k + 2];
+        }
+        unsigned int o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int v = (k0 * hrow[0][k] + k1 * hrow[1][k] + k2 * hrow[2][k] + (1 << 15)) >> 16;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            o |= (unsigned)v << (8 * k);
+            local += (unsigned)v;
+        }
+        *(unsigned int*)(dst + (size_t)y * W + x) = o;
+    }
+    __shared__ unsigned long long part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(sum, t);
+    }
+}
+
 // ---- CLAHE pass 1: per-tile histograms of lut[src] over the reflect-101 extended image (tiles tw x th, grid tx x ty)
 __global__ void __launch_bounds__(256) pp_clahe_hist_kernel(const uint8_t* __restrict__ src, int H, int W, const uint8_t* __restrict__ lut, int tw, int th,
                                                              int tx, int ty, unsigned int* __restrict__ hist) {
@@ -96,11 +137,9 @@ __global__ void __launch_bounds__(256) pp_clahe_hist_kernel(const uint8_t* __res
 // ---- CLAHE pass 2: dst = cvRound((L11*xa1 + L12*xa)*ya1 + (L21*xa1 + L22*xa)*ya), Lij = tile LUTs of v = lut[src]
 __global__ void __launch_bounds__(256) pp_clahe_apply_kernel(const uint8_t* __restrict__ src, int H, int W, const uint8_t* __restrict__ lut,
                                                               const uint8_t* __restrict__ tile_luts, int tw, int th, int tx, int ty,
-                                                              uint8_t* __restrict__ dst) {
+                                                              uint8_t* __restrict__ dst, int vec) {
     const float inv_th = 1.0f / (float)th, inv_tw = 1.0f / (float)tw;
-    const size_t total = (size_t)H * W;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    auto pixel = [&](int y, int x, int raw) {
         const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
         int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
         const float ya = tyf - (float)ty1, xa = txf - (float)tx1;
@@ -108,12 +147,30 @@ __global__ void __launch_bounds__(256) pp_clahe_apply_kernel(const uint8_t* __re
         int ty2 = ty1 + 1, tx2 = tx1 + 1;
         ty1 = ty1 < 0 ? 0 : ty1; tx1 = tx1 < 0 ? 0 : tx1;
         ty2 = ty2 > ty - 1 ? ty - 1 : ty2; tx2 = tx2 > tx - 1 ? tx - 1 : tx2;
-        const int v = lut[src[i]];
+        const int v = lut[raw];
         const float l11 = (float)tile_luts[(ty1 * tx + tx1) * 256 + v], l12 = (float)tile_luts[(ty1 * tx + tx2) * 256 + v];
         const float l21 = (float)tile_luts[(ty2 * tx + tx1) * 256 + v], l22 = (float)tile_luts[(ty2 * tx + tx2) * 256 + v];
         const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
         const int r = __float2int_rn(res);                       // cvRound: round half to even
-        dst[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        return (unsigned)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    };
+    if (vec) {                                                   // W % 4 == 0: dword load / store, four pixels per thread
+        const int W4 = W >> 2;
+        const size_t total = (size_t)H * W4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int y = (int)(i / W4), x = (int)(i - (size_t)y * W4) << 2;
+            const unsigned int c = *(const unsigned int*)(src + (size_t)y * W + x);
+            unsigned int o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o |= pixel(y, x + k, (c >> (8 * k)) & 255u) << (8 * k);
+            *(unsigned int*)(dst + (size_t)y * W + x) = o;
+        }
+        return;
+    }
+    const size_t total = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        dst[i] = (uint8_t)pixel(y, x, src[i]);
     }
 }
 
@@ -142,14 +199,58 @@ __global__ void __launch_bounds__(256) pp_box_pass_kernel(const uint8_t* __restr
     }
 }
 
+// ---- the same for box radius 0 (PIL GaussianBlur radius 1: box radius 0.25), four pixels per thread, W % 4 == 0:
+// out = (v*ww + (left + right)*fw + 2^23) >> 24 with edge replication, dword loads / stores
+__global__ void __launch_bounds__(256) pp_box0_x4_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W, int vertical,
+                                                          unsigned int ww, unsigned int fw) {
+    const int W4 = W >> 2;
+    const size_t total = (size_t)H * W4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W4), x = (int)(i - (size_t)y * W4) << 2;
+        const uint8_t* row = src + (size_t)y * W;
+        const unsigned int c = *(const unsigned int*)(row + x);
+        unsigned int v[4] = {c & 255u, (c >> 8) & 255u, (c >> 16) & 255u, c >> 24}, a[4], b[4];
+        if (vertical) {
+            const unsigned int up = *(const unsigned int*)(src + (size_t)(y > 0 ? y - 1 : 0) * W + x);
+            const unsigned int dn = *(const unsigned int*)(src + (size_t)(y + 1 < H ? y + 1 : H - 1) * W + x);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = (up >> (8 * k)) & 255u; b[k] = (dn >> (8 * k)) & 255u; }
+        } else {
+            a[0] = row[x > 0 ? x - 1 : 0]; a[1] = v[0]; a[2] = v[1]; a[3] = v[2];
+            b[0] = v[1]; b[1] = v[2]; b[2] = v[3]; b[3] = row[x + 4 < W ? x + 4 : W - 1];
+        }
+        unsigned int o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= (((v[k] * ww + (a[k] + b[k]) * fw) + (1u << 23)) >> 24) << (8 * k);
+        *(unsigned int*)(dst + (size_t)y * W + x) = o;
+    }
+}
+
 // ---- PIL UnsharpMask combine: diff = in - blur; |diff| > threshold ? clip8(in + diff * percent / 100) : in
 __global__ void __launch_bounds__(256) pp_unsharp_kernel(const uint8_t* __restrict__ in, const uint8_t* __restrict__ blur, uint8_t* __restrict__ dst,
                                                           size_t total, int percent, int threshold) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t t4 = total >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < t4; i += (size_t)gridDim.x * 256) {
+        const unsigned int av = ((const unsigned int*)in)[i], bv = ((const unsigned int*)blur)[i];
+        unsigned int ov = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (av >> (8 * k)) & 255, diff = a - (int)((bv >> (8 * k)) & 255);
+            int o = a;
+            if (abs(diff) > threshold) {
+                o = a + diff * percent / 100;                    // C integer division: truncates towards zero
+                o = o < 0 ? 0 : (o > 255 ? 255 : o);
+            }
+            ov |= (unsigned)o << (8 * k);
+        }
+        ((unsigned int*)dst)[i] = ov;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {          // tail pixels
+        const size_t i = (t4 << 2) + threadIdx.x;
         const int a = in[i], diff = a - (int)blur[i];
         int o = a;
         if (abs(diff) > threshold) {
-            o = a + diff * percent / 100;                        // C integer division: truncates towards zero
+            o = a + diff * percent / 100;
             o = o < 0 ? 0 : (o > 255 ? 255 : o);
         }
         dst[i] = (uint8_t)o;
@@ -172,6 +273,11 @@ hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst
     return hipGetLastError();
 }
 hipError_t launch_pp_gauss3(const uint8_t* src, int H, int W, uint8_t* dst, int k0, int k1, int k2, unsigned long long* sum, hipStream_t s) {
+    if ((W & 3) == 0 && W >= 8 && (((size_t)src | (size_t)dst) & 3) == 0) {
+        const int g4 = pp_grid((size_t)H * (W >> 2)) > 4096 ? 4096 : pp_grid((size_t)H * (W >> 2));
+        hipLaunchKernelGGL(pp_gauss3_x4_kernel, dim3(g4), dim3(256), 0, s, src, H, W, dst, k0, k1, k2, sum);
+        return hipGetLastError();
+    }
     const int grid = pp_grid((size_t)H * W) > 4096 ? 4096 : pp_grid((size_t)H * W);      // grid-stride: at most 4096 atomics on `sum`
     hipLaunchKernelGGL(pp_gauss3_kernel, dim3(grid), dim3(256), 0, s, src, H, W, dst, k0, k1, k2, sum);
     return hipGetLastError();
@@ -183,15 +289,21 @@ hipError_t launch_pp_clahe_hist(const uint8_t* src, int H, int W, const uint8_t*
 }
 hipError_t launch_pp_clahe_apply(const uint8_t* src, int H, int W, const uint8_t* lut, const uint8_t* tile_luts, int tw, int th, int tx, int ty,
                                  uint8_t* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pp_clahe_apply_kernel, dim3(pp_grid((size_t)H * W)), dim3(256), 0, s, src, H, W, lut, tile_luts, tw, th, tx, ty, dst);
+    const int vec = (W & 3) == 0 && (((size_t)src | (size_t)dst) & 3) == 0;
+    hipLaunchKernelGGL(pp_clahe_apply_kernel, dim3(pp_grid(vec ? (size_t)H * (W >> 2) : (size_t)H * W)), dim3(256), 0, s, src, H, W, lut, tile_luts, tw,
+                       th, tx, ty, dst, vec);
     return hipGetLastError();
 }
 hipError_t launch_pp_box_pass(const uint8_t* src, uint8_t* dst, int H, int W, int vertical, int r, unsigned int ww, unsigned int fw, hipStream_t s) {
+    if (r == 0 && (W & 3) == 0 && (((size_t)src | (size_t)dst) & 3) == 0) {
+        hipLaunchKernelGGL(pp_box0_x4_kernel, dim3(pp_grid((size_t)H * (W >> 2))), dim3(256), 0, s, src, dst, H, W, vertical, ww, fw);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pp_box_pass_kernel, dim3(pp_grid((size_t)H * W)), dim3(256), 0, s, src, dst, H, W, vertical, r, ww, fw);
     return hipGetLastError();
 }
 hipError_t launch_pp_unsharp(const uint8_t* in, const uint8_t* blur, uint8_t* dst, size_t total, int percent, int threshold, hipStream_t s) {
-    hipLaunchKernelGGL(pp_unsharp_kernel, dim3(pp_grid(total)), dim3(256), 0, s, in, blur, dst, total, percent, threshold);
+    hipLaunchKernelGGL(pp_unsharp_kernel, dim3(pp_grid((total >> 2) + 1)), dim3(256), 0, s, in, blur, dst, total, percent, threshold);
     return hipGetLastError();
 }
 hipError_t launch_pp_lut(const uint8_t* src, uint8_t* dst, const uint8_t* lut, size_t total, hipStream_t s) {
