@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     // per-lane source pixel of each 64-pixel patch block (or -1: padding -> zero page)
     int spix[NPB];
     const int pw_magic = (65536 + a.PW - 1) / a.PW;     // pix / PW == (pix * magic) >> 16 exactly for pix < 448, PW <= 66
-    const int stack_magic = (65536 + a.stack) / (a.stack + 1);   // same bound for the stacked phase images (checked by launch_conv)
+    const int stack_magic = ((1 << 20) + a.stack) / (a.stack + 1);   // vy / (stack+1) == (vy * magic) >> 20 (launch_conv checks the exactness bound)
     auto geom_pix = [&](const Geo& g) {
         const int iy0 = g.oy0 - 1, ix0 = g.ox0 - 1;
 #pragma unroll
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             if (sub > 1) {
                 // virtual row -> (phase q, row inside the phase image); row a.stack of every phase is the shared zero row
                 const int vy = ly < 0 ? 0 : ly;
-                const int q = (vy * stack_magic) >> 16;
+                const int q = (vy * stack_magic) >> 20;
                 ly = vy - q * (a.stack + 1);
                 sph = q / sub;
                 spw = q - sph * sub;
@@ -1132,7 +1132,11 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             const long long cost = (long long)cdiv(d * d * (LH + 1), th) * cdiv(LW, tw);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = npb * 64; }
         }
-        if (best > 0 && (a.C0 + a.C1 == p.Cin_pad) && !(a.C0 & 31) && !(a.C1 & 31) && d * d * (LH + 1) + 18 < 448 && LH + 1 <= 66) {
+        if (best > 0 && (a.C0 + a.C1 == p.Cin_pad) && !(a.C0 & 31) && !(a.C1 & 31) && [&] {
+                // the kernel divides a virtual row by LH+1 as (vy * ceil(2^20 / (LH+1))) >> 20: exact while vy * (magic * (LH+1) - 2^20) < 2^20
+                const long long vmax = (long long)d * d * (LH + 1) + 18, magic = ((1LL << 20) + LH) / (LH + 1);
+                return vmax * (magic * (LH + 1) - (1LL << 20)) < (1LL << 20) && vmax * magic < (1LL << 31);
+            }()) {
             a.sub = d;
             a.stack = LH;
             a.tiles_x = cdiv(LW, a.TW);

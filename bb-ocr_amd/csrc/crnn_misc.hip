@@ -181,26 +181,31 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
     const uint8_t* src = (tall ? hscratch : scratch) + d.a_off;
     const uint8_t* lut = (!tall && d.lut_off >= 0) ? luts + d.lut_off : nullptr;
     uint16_t* dst = out + (size_t)d.slot * 64 * imgW;
-    const int total = 64 * imgW;
+    // 16 x 256 threads per crop = 64 rows x 64 threads: thread -> (row y, column phase), columns strided by 64: no per-element
+    // division, the vertical PIL coefficients (tall boxes) once per row
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int y = t >> 6, x0 = t & 63;
+    if (y >= 64) return;
     int kk[PIL_MAXK];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int x = i % imgW, y = i / imgW;
+    int ymin = 0, n = 0;
+    const bool vert = tall && d.rh != 64;
+    if (vert) n = pil_coeffs(d.rh, 64, y, ymin, kk);
+    uint16_t* drow = dst + (size_t)y * imgW;
+    for (int x = x0; x < imgW; x += 64) {
         const int xs = x < d.fw ? x : d.fw - 1;
         int v;
         if (!tall) {
             v = src[(size_t)y * d.rw + xs];
             if (lut) v = lut[v];
-        } else if (d.rh == 64) {
+        } else if (!vert) {
             v = src[(size_t)y * d.fw + xs];
         } else {
-            int ymin;
-            const int n = pil_coeffs(d.rh, 64, y, ymin, kk);
             long long acc = 1LL << (PIL_PREC - 1);
             for (int k = 0; k < n; ++k) acc += (long long)src[(size_t)(ymin + k) * d.fw + xs] * kk[k];
             v = pil_clip8(acc);
         }
-        const float t = ((float)v / 255.0f - 0.5f) / 0.5f;
-        dst[i] = f32_to_bf16_bits(t);
+        const float tv = ((float)v / 255.0f - 0.5f) / 0.5f;
+        drow[x] = f32_to_bf16_bits(tv);
     }
 }
 
