@@ -254,7 +254,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 const size_t prow = (size_t)(n * POH + py) * POW * a.pool_cs;
                 if (a.pool_mode == 1) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], 1));
+                    for (int i = 0; i < 16; ++i)      // neighbour lane l^1 by DPP quad_perm [1,0,3,2]: one VALU op instead of a ds_bpermute
+                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[i]), 0xB1, 0xF, 0xF, true)));
                     const int px = ox >> 1;
                     u32x4 lo, hi;
                     pack_runs(m, lo, hi);
