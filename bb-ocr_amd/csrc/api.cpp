@@ -529,7 +529,8 @@ static void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, c
         craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
         const size_t per_page = std::max<size_t>(c->arena.off, 1);
         const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)96 << 30) / per_page));
-        const int tail = (after_sub && B >= 24 && cap > 8) ? 8 : 0;
+        static const int tail_pages = [] { const char* e = getenv("BBOCR_DET_TAIL"); return e ? atoi(e) : 8; }();   // A/B knob
+        const int tail = (after_sub && B >= 24 && cap > tail_pages && tail_pages > 0) ? tail_pages : 0;
         const int body = B - tail, nbig = cdiv(body, cap);
         for (int i = 0; i < nbig; ++i) passes.push_back(body / nbig + (i < body % nbig ? 1 : 0));
         if (tail) passes.push_back(tail);
