@@ -80,6 +80,7 @@ struct bbocr_ctx {
     bbocr_config cfg{};
     hipStream_t stream = nullptr;
     DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
+    unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
     hipStream_t cur = nullptr;                // stream the layer helpers launch on (stream, or a recogniser side stream)
     hipStream_t rstream[4] = {nullptr, nullptr, nullptr, nullptr};   // recogniser conv stacks of different width buckets run side by side
     hipEvent_t rjoin[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -912,7 +913,7 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
         c->ctc_out_idx.ensure(rows * 4);
         c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
         HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
-                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream));
+                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask));
         std::vector<int> oidx(rows);
         std::vector<CtcOut> oo(nseq);
         HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -954,6 +955,8 @@ static double percentile_u8(const unsigned int* hist, size_t n, double q) {
 static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p,
                            std::vector<BoxJob>& jobs, std::vector<int>& box_off) {
     if (!c->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
+    if (p.ignore_mask[0] & 1u) fail(BBOCR_ERR_ARG, "the CTC blank (class 0) cannot be ignored");
+    for (int i = 0; i < 4; ++i) c->ignore_mask[i] = p.ignore_mask[i];
     jobs.clear();
     box_off.assign(B + 1, 0);
     for (int b = 0; b < B; ++b) {
@@ -1651,7 +1654,8 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
     });
 }
 
-int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf) {
+int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf,
+                 const unsigned int* ignore_mask) {
     return guarded(ctx, [&] {
         if (!dev_logits || !text_off || !text_idx || !conf || n <= 0 || T <= 0 || C <= 0 || C > cs) fail(BBOCR_ERR_ARG, "bad ctc arguments");
         const size_t rows = (size_t)n * T;
@@ -1664,7 +1668,7 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
         ctx->seq_tables.ensure(seqs.size() * 4);
         HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(launch_ctc(dev_logits, rows, C, cs, (const int*)ctx->seq_tables.p, n, (int*)ctx->ctc_idx.p, (float*)ctx->ctc_pmax.p,
-                          (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p, ctx->stream));
+                          (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p, ctx->stream, ignore_mask));
         std::vector<int> oidx(rows);
         std::vector<CtcOut> oo(n);
         HIPCHK(hipMemcpyAsync(oidx.data(), ctx->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -109,7 +109,7 @@ int lstm8_xproj_channel(int dir, int gate, int unit);
 struct CtcOut { int len; int cnt; float prod; int pad; };
 // seqs_dev: int2 per sequence {first row, T}; logits fp32 [rows, cs]; out_idx is row-indexed like the pool
 hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,
-                      int* out_idx, CtcOut* out, hipStream_t s);
+                      int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore = nullptr);   // ignore: 4 x 32-bit class mask or null
 
 // ------------------------------------------------------------------ OCR pre-processing chain (preproc.hip), SURVEY 8 row f2
 hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const short* cx, const int* y0,

@@ -78,6 +78,78 @@ def reformat_input(image, device_gray=False):
     raise ValueError("Invalid input type. Supporting format = string(file path or url), bytes, numpy array")
 
 
+def ignore_mask(character, lang_char, allowlist=None, blocklist=None):
+    """easyocr.Reader.recognize's ``ignore_char`` rule as the 128-bit class mask of ``bbocr_params.ignore_mask``: with an allowlist
+    every character outside it, else the blocklist, else the characters of the model that are not in the language list (none for
+    ``['en']`` + english_g2).  Class index = position in ``character`` (0 is the CTC blank and is never ignored)."""
+    if allowlist:
+        ignore = set(character[1:]) - set(allowlist)
+    elif blocklist:
+        ignore = set(blocklist)
+    else:
+        ignore = set(character[1:]) - set(lang_char)
+    words = [0, 0, 0, 0]
+    for i, ch in enumerate(character):
+        if i and ch in ignore:
+            words[i >> 5] |= 1 << (i & 31)
+    return words
+
+
+def get_paragraph(raw_result, x_ths=1, y_ths=0.5, mode="ltr"):
+    """easyocr/utils.py::get_paragraph: greedy clustering of result boxes into paragraphs (a box joins the current group when one
+    of its x extremes and one of its y extremes fall inside the group's extent grown by x_ths / y_ths mean heights), then reading
+    order inside a group: repeatedly the left-most (ltr) box among those within 0.4 mean heights of the top-most centre.
+    Returns ``[[box, text]]`` (no confidence), like upstream."""
+    box_group = []
+    for box in raw_result:
+        all_x = [int(coord[0]) for coord in box[0]]
+        all_y = [int(coord[1]) for coord in box[0]]
+        min_x, max_x, min_y, max_y = min(all_x), max(all_x), min(all_y), max(all_y)
+        box_group.append([box[1], min_x, max_x, min_y, max_y, max_y - min_y, 0.5 * (min_y + max_y), 0])
+    current_group = 1
+    while len([b for b in box_group if b[7] == 0]) > 0:
+        box_group0 = [b for b in box_group if b[7] == 0]
+        if len([b for b in box_group if b[7] == current_group]) == 0:
+            box_group0[0][7] = current_group
+        else:
+            cur = [b for b in box_group if b[7] == current_group]
+            mean_height = float(np.mean([b[5] for b in cur]))
+            min_gx = min(b[1] for b in cur) - x_ths * mean_height
+            max_gx = max(b[2] for b in cur) + x_ths * mean_height
+            min_gy = min(b[3] for b in cur) - y_ths * mean_height
+            max_gy = max(b[4] for b in cur) + y_ths * mean_height
+            add_box = False
+            for b in box_group0:
+                same_h = (min_gx <= b[1] <= max_gx) or (min_gx <= b[2] <= max_gx)
+                same_v = (min_gy <= b[3] <= max_gy) or (min_gy <= b[4] <= max_gy)
+                if same_h and same_v:
+                    b[7] = current_group
+                    add_box = True
+                    break
+            if not add_box:
+                current_group += 1
+    result = []
+    for i in sorted(set(b[7] for b in box_group)):
+        cur = [b for b in box_group if b[7] == i]
+        mean_height = float(np.mean([b[5] for b in cur]))
+        min_gx, max_gx = min(b[1] for b in cur), max(b[2] for b in cur)
+        min_gy, max_gy = min(b[3] for b in cur), max(b[4] for b in cur)
+        text = ""
+        while len(cur) > 0:
+            highest = min(b[6] for b in cur)
+            candidates = [b for b in cur if b[6] < highest + 0.4 * mean_height]
+            if mode == "ltr":
+                key = min(b[1] for b in candidates)
+                best = [b for b in candidates if b[1] == key][-1]
+            else:
+                key = max(b[2] for b in candidates)
+                best = [b for b in candidates if b[2] == key][-1]
+            text += " " + best[0]
+            cur.remove(best)
+        result.append([[[min_gx, min_gy], [max_gx, min_gy], [max_gx, max_gy], [min_gx, max_gy]], text[1:]])
+    return result
+
+
 class Reader:
     """Drop-in for ``easyocr.Reader`` (English ``english_g2`` recogniser + CRAFT detector) on one MI355X."""
 
@@ -150,6 +222,8 @@ class Reader:
         for k in _DET_KW + ("contrast_ths", "adjust_contrast"):
             if k in kw and kw[k] is not None:
                 setattr(p, k, kw[k])
+        for i, w in enumerate(ignore_mask(self.character, self.lang_char, kw.get("allowlist"), kw.get("blocklist"))):
+            p.ignore_mask[i] = w
         return p
 
     def _to_dev(self, arr):
@@ -214,6 +288,10 @@ class Reader:
         res = C.POINTER(_lib.bbocr_result)()
         gp = C.c_void_p(gray_dev.data_ptr()) if gray_dev is not None else C.c_void_p(None)
         self._check(self._lib.bbocr_readtext_batch(self._h, C.c_void_p(rgb_dev.data_ptr()), gp, B, H, W, C.byref(p), C.byref(res)))
+        if kw.get("paragraph"):
+            # Reader.readtext tail: get_paragraph on the raw result, then detail == 0 keeps the text only
+            pages = [get_paragraph(page, x_ths=kw.get("x_ths", 1.0), y_ths=kw.get("y_ths", 0.5), mode="ltr") for page in self._collect(res, 1)]
+            return [[item[1] for item in page] for page in pages] if kw.get("detail", 1) == 0 else pages
         return self._collect(res, kw.get("detail", 1))
 
     def readtext(self, image, decoder="greedy", beamWidth=5, batch_size=1, workers=0, allowlist=None, blocklist=None, detail=1,
@@ -226,15 +304,15 @@ class Reader:
         img, grey = reformat_input(image, device_gray=True)
         kw = dict(min_size=min_size, contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, text_threshold=text_threshold,
                   low_text=low_text, link_threshold=link_threshold, canvas_size=canvas_size, mag_ratio=mag_ratio, slope_ths=slope_ths,
-                  ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail)
+                  ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail,
+                  allowlist=allowlist, blocklist=blocklist, paragraph=paragraph, x_ths=x_ths, y_ths=y_ths)
         return self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]) if grey is not None else None, **kw)[0]
 
     def readtext_batched(self, image, n_width=None, n_height=None, **kw):
         """List (or 4-D array) of pages -> list of per-page results.  Equal-size pages share one device batch."""
-        self._unsupported(kw.pop("decoder", "greedy"), kw.pop("allowlist", None), kw.pop("blocklist", None), kw.pop("rotation_info", None),
-                          kw.pop("paragraph", False), kw.pop("output_format", "standard"))
-        for k in ("beamWidth", "batch_size", "workers", "filter_ths", "y_ths", "x_ths", "threshold", "bbox_min_score", "bbox_min_size",
-                  "max_candidates"):
+        self._unsupported(kw.pop("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.pop("rotation_info", None),
+                          kw.get("paragraph", False), kw.pop("output_format", "standard"))
+        for k in ("beamWidth", "batch_size", "workers", "filter_ths", "threshold", "bbox_min_score", "bbox_min_size", "max_candidates"):
             kw.pop(k, None)
         pages = [reformat_input(im) for im in image]
         if n_width is not None and n_height is not None:
@@ -275,7 +353,9 @@ class Reader:
     def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", detail=1, paragraph=False,
                   contrast_ths=0.1, adjust_contrast=0.5, reformat=True, **_ignored):
         """``Reader.recognize`` for explicit boxes of one gray page."""
-        self._unsupported(decoder, None, None, None, paragraph, "standard")
+        self._unsupported(decoder, None, None, None, False, "standard")
+        if paragraph:
+            raise NotImplementedError("recognize(paragraph=True) is not implemented; readtext(paragraph=True) is")
         if reformat:
             _, img_cv_grey = reformat_input(img_cv_grey)
         H, W = img_cv_grey.shape
@@ -340,6 +420,6 @@ class Reader:
     def _unsupported(decoder, allowlist, blocklist, rotation_info, paragraph, output_format):
         if decoder != "greedy":
             raise NotImplementedError("only decoder='greedy' is implemented (the reference never passes another one)")
-        if allowlist or blocklist or rotation_info or paragraph or output_format != "standard":
-            raise NotImplementedError("allowlist/blocklist/rotation_info/paragraph/output_format are not implemented yet "
+        if rotation_info or output_format != "standard":
+            raise NotImplementedError("rotation_info / output_format are not implemented "
                                       "(the reference calls readtext(path, paragraph=False, batch_size=1, workers=0))")

@@ -69,7 +69,8 @@ typedef struct bbocr_params {
     double adjust_contrast;/* 0.5 */
     int canvas_size;       /* 2560 */
     int min_size;          /* 20 */
-    int reserved[4];
+    unsigned int ignore_mask[4]; /* recognizer_predict's ignore_idx as a bit mask over class indices 0..127 (allowlist / blocklist):
+                                  * those classes are zeroed and the rest renormalised before the arg-max; 0 = none (english_g2 default) */
 } bbocr_params;
 
 /* output of detection (easyocr.Reader.detect): per image horizontal_list / free_list, plus the ungrouped polygons */
@@ -157,8 +158,10 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
                     uint16_t* dev_pool_out);
 /* recogniser network only: crops bf16 [n,64,imgW] (device, already normalised) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);
-/* greedy CTC on logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n] */
-int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf);
+/* greedy CTC on logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n]; ignore_mask: 4 x 32-bit class mask
+ * (bbocr_params::ignore_mask) or NULL */
+int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf,
+                 const unsigned int* ignore_mask);
 /* cv2.resize(INTER_LINEAR) on uint8 [N,sh,sw,C] -> [N,dh,dw,C] (device) */
 int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw);
 /* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] for the boxes whose padded width

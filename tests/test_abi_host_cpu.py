@@ -298,3 +298,27 @@ def test_extractor_downscale_rule_and_batching(tmp_path):
     texts = eb.extract_texts(fr, [big, small, big, tmp_path / "missing.png"], [1, 2, 0, 3, 7])
     assert texts == {1: "", 2: "w2400 x", 0: "w1600 x", 3: ""}
     assert sorted(fr.batches) == sorted([(1, 300, 400, 3), (1, 800, 2400, 3), (1, 533, 1600, 3)])
+
+
+def test_paragraph_and_ignore_mask_rules():
+    """f4: easyocr/utils.py::get_paragraph (grouping + reading order) and Reader.recognize's ignore_char rule."""
+    import bb_ocr_amd
+    from bb_ocr_amd.reader import get_paragraph, ignore_mask
+
+    def box(x0, y0, x1, y1):
+        return [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+
+    res = [(box(10, 10, 60, 30), "Hello", 0.9), (box(70, 12, 130, 31), "world", 0.8),      # line 1
+           (box(12, 36, 90, 56), "second", 0.9), (box(100, 38, 140, 57), "line", 0.7),      # line 2, same paragraph
+           (box(400, 300, 460, 320), "far", 0.9), (box(470, 301, 520, 321), "away", 0.9)]   # another paragraph
+    out = get_paragraph(res)
+    assert [o[1] for o in out] == ["Hello world second line", "far away"]
+    assert out[0][0] == [[10, 10], [140, 10], [140, 57], [10, 57]] and len(out[0]) == 2
+    assert [o[1] for o in get_paragraph(res, x_ths=0.1, y_ths=0.1)] == ["Hello", "world", "second", "line", "far", "away"]
+    ch, lang = bb_ocr_amd.CHARACTER, list(bb_ocr_amd.CHARSET)
+    assert ignore_mask(ch, lang) == [0, 0, 0, 0]
+    w = ignore_mask(ch, lang, allowlist="ab")
+    kept = [ch[i] for i in range(1, len(ch)) if not (w[i >> 5] >> (i & 31)) & 1]
+    assert kept == sorted(kept, key=ch.index) and set(kept) == {"a", "b"} and not (w[0] & 1)
+    w = ignore_mask(ch, lang, blocklist="xyz")
+    assert {ch[i] for i in range(len(ch)) if (w[i >> 5] >> (i & 31)) & 1} == {"x", "y", "z"}

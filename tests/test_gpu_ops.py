@@ -136,13 +136,32 @@ def test_ctc_matches_oracle(reader):
     off = (C.c_int * (n + 1))()
     idx = (C.c_int * (n * T))()
     conf = (C.c_double * n)()
-    reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf))
+    reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, None))
     ref = recog.predict_from_logits(logits[:, :, :Cn])
     for i in range(n):
         text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
         assert text == ref[i][0]
         assert conf[i] == pytest.approx(float(ref[i][1]), rel=2e-5, abs=1e-12)
     assert off[1] - off[0] == 0 and conf[0] == 0.0
+    # f4: allowlist / blocklist = recognizer_predict's ignore_idx (zeroed classes, renormalised rows)
+    import bb_ocr_amd
+    from bb_ocr_amd.reader import ignore_mask
+
+    for kw in ({"allowlist": "0123456789"}, {"blocklist": "aeiouAEIOU -"}):
+        words = ignore_mask(bb_ocr_amd.CHARACTER, list(bb_ocr_amd.CHARSET), **kw)
+        ign = [i for i in range(Cn) if (words[i >> 5] >> (i & 31)) & 1]
+        assert 0 not in ign and len(ign) > 0
+        mask = (C.c_uint * 4)(*words)
+        reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, mask))
+        ref = recog.predict_from_logits(logits[:, :, :Cn], ignore_idx=ign)
+        for i in range(n):
+            text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
+            assert text == ref[i][0]
+            assert conf[i] == pytest.approx(float(ref[i][1]), rel=2e-5, abs=1e-12)
+            if "allowlist" in kw:
+                assert set(text) <= set(kw["allowlist"])
+            else:
+                assert not (set(text) & set(kw["blocklist"]))
 
 
 def test_preprocess_chain_bit_exact_vs_oracle(reader):

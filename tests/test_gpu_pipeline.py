@@ -284,3 +284,18 @@ def test_extractor_batching_and_tesseract_shim(reader, tmp_path):
         assert texts[i] == " ".join(r[1] for r in reader.readtext(str(p)))
     s = ts.image_to_string(Image.open(paths[0]), reader=reader)
     assert s.endswith("\n") and len(s.strip().split("\n")) == 5
+
+
+def test_paragraph_and_allowlist_modes(reader):
+    """f4 on the GPU path: paragraph=True returns [box, text] groups covering the same words; an allowlist restricts the alphabet."""
+    from bb_ocr_amd import synth
+
+    img = synth.page(321, width=640, height=384, lines=5, margin=24)[0]
+    plain = reader.readtext(img)
+    para = reader.readtext(img, paragraph=True)
+    assert len(para) >= 1 and all(len(p) == 2 for p in para)
+    assert sorted(" ".join(p[1] for p in para).split()) == sorted(" ".join(r[1] for r in plain).split())
+    assert reader.readtext(img, paragraph=True, detail=0) == [p[1] for p in para]
+    digits = reader.readtext(img, allowlist="0123456789")
+    assert [d[0] for d in digits] == [r[0] for r in plain]                        # same boxes
+    assert all(set(d[1]) <= set("0123456789") for d in digits) and any(d[1] for d in digits)
