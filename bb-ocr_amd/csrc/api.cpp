@@ -94,7 +94,7 @@ struct bbocr_ctx {
 
     // ---- optional per-launch timing of the conv_mfma kernel (HIP events on this context's stream)
     struct ProfRec { hipEvent_t e0, e1; double flops; int group; };
-    bool profiling = false;
+    int profiling = 0;                        // 0 off, 1 = time the detector's conv launches (group 0), 2 = also the recogniser's
     int prof_group = 0;                     // 0 = detector, 1 = recogniser
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -346,7 +346,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
 // ------------------------------------------------------------------------------------------------ conv helper
 static void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
     a.zero = c->zero_page;
-    if (!c->profiling) {
+    if (c->profiling == 0 || (c->profiling == 1 && c->prof_group != 0)) {
         HIPCHK(launch_conv(p, a, c->cur));
         return;
     }
@@ -1539,7 +1539,7 @@ void bbocr_free_result(bbocr_result* r) {
 int bbocr_set_profiling(bbocr_ctx* ctx, int on) {
     if (!ctx) return BBOCR_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = on != 0;
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     for (int g = 0; g < 2; ++g) { ctx->prof_ms[g] = 0; ctx->prof_flops[g] = 0; ctx->prof_launches[g] = 0; }
     return BBOCR_OK;
 }

@@ -272,7 +272,7 @@ class Reader:
 
     def set_profiling(self, on: bool):
         """Time every conv_mfma launch with HIP events on the library's stream (bench.py roofline leg)."""
-        self._check(self._lib.bbocr_set_profiling(self._h, int(bool(on))))
+        self._check(self._lib.bbocr_set_profiling(self._h, int(on)))      # 0 off, 1/True detector launches, 2 also the recogniser's
 
     def conv_profile(self, group: int):
         """-> (sum of launch ms, sum of algorithmic flops, launches) for group 0 (detector) / 1 (recogniser)."""

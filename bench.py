@@ -97,7 +97,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
         log(f"warm-up step done: {reader.stage_times()}")
-    reader.set_profiling(True)
+    reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -117,7 +117,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     conv_ms, conv_flops, conv_launches = reader.conv_profile(0)
-    rec_ms, rec_flops, rec_launches = reader.conv_profile(1)
     n_boxes = sum(len(p) for p in out)
     n_chars = sum(len(t) for p in out for _, t, _ in p)
 
@@ -163,8 +162,8 @@ def main():
         "traffic": traffic, "traffic_source": traffic_src,
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
         "algorithmic_gflop_per_page": conv_flops / 1e9 / max(B * args.steps, 1),
-        "recogniser_convs": {"achieved": rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0, "launches": rec_launches,
-                             "ms_per_step": rec_ms / args.steps},
+        # (the recogniser's ~500 launches per step overlap on side streams and are not event-timed in the measured run:
+        #  Reader.set_profiling(2) + conv_profile(1) gives their busy time)
     }
     log(f"GPU legs done: {pages / dt:.1f} images/s; CPU baseline next")
     if world == 1 and args.cpu_pages > 0:

@@ -135,7 +135,8 @@ void bbocr_free_result(bbocr_result* r);
 int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n);
 
 /* Per-launch timing of the dominant kernel (conv_mfma) with HIP events recorded on the context's stream.
- * group 0 = detector convs, 1 = recogniser convs/GEMMs.  Totals accumulate from bbocr_set_profiling(ctx, 1) on:
+ * group 0 = detector convs, 1 = recogniser convs/GEMMs.  on = 1 times group 0 only (54 launches per 64-page step: the roofline
+ * leg of bench.py), on = 2 both groups (about ten times as many events: ~1.5 % of a step), 0 = off.  Totals accumulate from the call on:
  * ms = sum of launch durations, flops = sum of ALGORITHMIC flops (2*N*OH*OW*Cout*Cin*KH*KW, unpadded). */
 int bbocr_set_profiling(bbocr_ctx* ctx, int on);
 int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches);
