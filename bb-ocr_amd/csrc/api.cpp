@@ -81,9 +81,7 @@ struct bbocr_ctx {
     hipStream_t stream = nullptr;
     DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
     unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
-    hipStream_t cur = nullptr;                // stream the layer helpers launch on (stream, or a recogniser side stream)
-    hipStream_t rstream[4] = {nullptr, nullptr, nullptr, nullptr};   // recogniser conv stacks of different width buckets run side by side
-    hipEvent_t rjoin[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cur = nullptr;                // stream the layer helpers launch on
     hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
     std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
     hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
@@ -766,6 +764,33 @@ static void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, 
     if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->cur));
 }
 
+// The same conv stack over the WIDE image of a recognition pass: every crop side by side with 4 zero columns between
+// neighbours (CropDesc::slot = first column), so each layer is ONE launch over [H, Wt] whatever the mix of width buckets.  The
+// separator columns are each layer's zero padding; convolutions write into them, so they are cleared on every layer output
+// (4 >> shift columns per crop).  The 3-row mean is gathered straight into every crop's pooled rows (CropDesc::pad_).
+static void crnn_features_wide(bbocr_ctx* c, const uint16_t* wide, int Wt, const CropDesc* descs, int first, int count, uint16_t* seq_v) {
+    Arena& ar = c->arena;
+    c->prof_group = 1;
+    Act c0{ar.alloc<uint16_t>((size_t)32 * (Wt / 2) * 32), 1, 32, Wt / 2, 32};
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(wide, c->r0_wb, c->r0_wb + 288, c0.p, 1, Wt, c->cur));
+    auto gaps = [&](const Act& a, int shift) {
+        if (!ar.dry) HIPCHK(launch_crnn_zero_gaps(a.p, descs, first, count, a.H, a.W, a.C, shift, c->cur));
+    };
+    gaps(c0, 1);
+    Act q1 = conv_pool_act(c, c->r1, c0, false, true, 64, 1, false, nullptr);
+    gaps(q1, 2);
+    Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
+    gaps(c2, 2);
+    Act q2 = conv_pool_act(c, c->r3, c2, false, true, 128, 2, false, nullptr);
+    gaps(q2, 2);
+    Act c4 = conv_act(c, c->r4, q2, false, nullptr, false, true, 256);
+    gaps(c4, 2);
+    Act q3 = conv_pool_act(c, c->r5, c4, false, true, 256, 2, false, nullptr);
+    gaps(q3, 2);
+    Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [1, 3, Wt/4 - 1, 256]
+    if (!ar.dry) HIPCHK(launch_rowmean3_gather(c6.p, c6.W, 256, descs, first, count, seq_v, c->cur));
+}
+
 // Sequence half of the recogniser over the POOLED time steps of every bucket (rows = sum n_i*T_i, padded to x256):
 // v bf16 [rows,256] (ctx->seq_v) -> logits fp32 [rows,112].  The two linear layers and both input projections are
 // single GEMMs over all rows; each BiLSTM layer is ONE launch whose workgroups carry their own sequence length.
@@ -823,6 +848,32 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
             }
         }
     }
+    // groups of chunks whose pooled rows fit one sequence pass; inside a group all crops sit side by side in ONE wide image
+    // (CropDesc::slot = first column, 4 zero columns after every crop; ::pad_ = first pooled row), so each CRNN layer is a single
+    // launch for the whole group instead of one per width bucket
+    constexpr int GAP = 4;
+    std::vector<size_t> group_end;            // chunk index one past each group
+    std::vector<size_t> group_rows, group_cols;
+    for (size_t g0 = 0; g0 < chunks.size();) {
+        size_t g1 = g0, rows = 0, cols = 0;
+        while (g1 < chunks.size() && (g1 == g0 || rows + (size_t)chunks[g1].n * chunks[g1].T <= max_rows)) {
+            RecChunk& ch = chunks[g1];
+            ch.row0 = rows;
+            for (int i = 0; i < ch.n; ++i) {
+                CropDesc& d = descs[ch.first + i];
+                if (cols > 0x7ff00000u) fail(BBOCR_ERR_OVERFLOW, "recogniser pass wider than 2^31 columns");
+                d.slot = (int)cols;
+                d.pad_ = (int)(rows + (size_t)i * ch.T);
+                cols += (size_t)ch.imgW + GAP;
+            }
+            rows += (size_t)ch.n * ch.T;
+            ++g1;
+        }
+        group_end.push_back(g1);
+        group_rows.push_back(rows);
+        group_cols.push_back(cols);
+        g0 = g1;
+    }
     c->crop_desc.ensure(descs.size() * sizeof(CropDesc));
     auto t0 = clk::now();
     HIPCHK(hipMemcpyAsync(c->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
@@ -838,41 +889,25 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
     c->times[3] += (float)ms_since(t0);
 
     size_t g0 = 0;
-    while (g0 < chunks.size()) {
-        // group of chunks whose pooled rows fit one sequence pass
-        size_t g1 = g0, rows = 0;
-        while (g1 < chunks.size() && (g1 == g0 || rows + (size_t)chunks[g1].n * chunks[g1].T <= max_rows)) {
-            chunks[g1].row0 = rows;
-            rows += (size_t)chunks[g1].n * chunks[g1].T;
-            ++g1;
-        }
+    for (size_t gi = 0; gi < group_end.size(); ++gi) {
+        const size_t g1 = group_end[gi], rows = group_rows[gi];
+        const int Wt = (int)group_cols[gi];
+        const int d_first = chunks[g0].first, d_count = chunks[g1 - 1].first + chunks[g1 - 1].n - d_first;
         const size_t rows_pad = align_up(rows, 256);
         c->seq_v.ensure(rows_pad * 256 * 2);
         c->seq_logits.ensure(rows_pad * 112 * 4);
         t0 = clk::now();
         std::vector<int> tiles, seqs;   // int4 / int2 tables
         std::vector<int> seq_k;         // sel position of each pooled sequence
-        // Conv stacks of the group's chunks: every chunk has its own activations (one arena sized by a dry pass over all of
-        // them) and the chunks are dealt round-robin over a few side streams, so the many small launches of narrow buckets
-        // overlap instead of each paying its own ramp-up and tail on an otherwise idle GPU.
         for (int pass = 0; pass < 2; ++pass) {
             c->arena.begin(pass == 0);
-            for (size_t ci = g0; ci < g1; ++ci) {
-                const RecChunk& ch = chunks[ci];
-                c->cur = c->rstream[(ci - g0) % 4];
-                uint16_t* crops = c->arena.alloc<uint16_t>((size_t)ch.n * 64 * ch.imgW);
-                if (pass == 1)
-                    HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, ch.first, ch.n, ch.imgW, any_warp, any_tall,
-                                        (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
-                                        (const uint8_t*)c->crop_luts.p, crops, 2, c->cur));
-                crnn_features(c, crops, ch.n, ch.imgW, (uint16_t*)c->seq_v.p + ch.row0 * 256);
-            }
-            c->cur = c->stream;
+            uint16_t* wide = c->arena.alloc<uint16_t>((size_t)64 * Wt);
+            if (pass == 1)
+                HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, d_first, d_count, 0, any_warp, any_tall,
+                                    (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
+                                    (const uint8_t*)c->crop_luts.p, wide, 2, c->stream, Wt, GAP));
+            crnn_features_wide(c, wide, Wt, (const CropDesc*)c->crop_desc.p, d_first, d_count, (uint16_t*)c->seq_v.p);
             if (pass == 0) c->arena.buf.ensure(c->arena.off);
-        }
-        for (int k = 0; k < 4; ++k) {
-            HIPCHK(hipEventRecord(c->rjoin[k], c->rstream[k]));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->rjoin[k], 0));
         }
         for (size_t ci = g0; ci < g1; ++ci) {
             const RecChunk& ch = chunks[ci];
@@ -1291,14 +1326,6 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
         }
         if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->rstream[0], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->rstream[1], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->rstream[2], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->rstream[3], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->rjoin[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->rjoin[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->rjoin[2], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->rjoin[3], hipEventDisableTiming) != hipSuccess ||
             hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
             delete c;
             return BBOCR_ERR_HIP;
@@ -1317,10 +1344,6 @@ void bbocr_destroy(bbocr_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    for (int k = 0; k < 4; ++k) {
-        if (c->rstream[k]) { (void)hipStreamSynchronize(c->rstream[k]); (void)hipStreamDestroy(c->rstream[k]); }
-        if (c->rjoin[k]) (void)hipEventDestroy(c->rjoin[k]);
-    }
     for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
     if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
     if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }

@@ -173,14 +173,18 @@ __global__ void __launch_bounds__(256) crop_pil_h_kernel(const CropDesc* __restr
 
 // stage B: (vertical PIL pass for tall boxes |  plain copy) + contrast LUT + ToTensor/normalise + right edge-replicate pad
 //   out bf16 [slot][64][imgW]
+// Output addressing: bucket tensor [slot][64][imgW] (row_stride = imgW, slot_stride = 64*imgW, gap = 0) or ONE wide image
+// [64][Wt] holding every crop side by side (row_stride = Wt, slot_stride = 1, slot = the crop's first column, gap zero columns
+// after it: the conv layers' zero padding between neighbours).
 __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restrict__ descs, int first, const uint8_t* __restrict__ scratch,
                                                          const uint8_t* __restrict__ hscratch, const uint8_t* __restrict__ luts,
-                                                         uint16_t* __restrict__ out, int imgW) {
+                                                         uint16_t* __restrict__ out, int row_stride, long long slot_stride, int gap) {
     const CropDesc d = descs[first + blockIdx.y];
     const bool tall = !(d.fw == d.rw && d.rh == 64);
     const uint8_t* src = (tall ? hscratch : scratch) + d.a_off;
     const uint8_t* lut = (!tall && d.lut_off >= 0) ? luts + d.lut_off : nullptr;
-    uint16_t* dst = out + (size_t)d.slot * 64 * imgW;
+    uint16_t* dst = out + (size_t)d.slot * (size_t)slot_stride;
+    const int imgW = d.imgW;
     // 16 x 256 threads per crop = 64 rows x 64 threads: thread -> (row y, column phase), columns strided by 64: no per-element
     // division, the vertical PIL coefficients (tall boxes) once per row
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -190,7 +194,8 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
     int ymin = 0, n = 0;
     const bool vert = tall && d.rh != 64;
     if (vert) n = pil_coeffs(d.rh, 64, y, ymin, kk);
-    uint16_t* drow = dst + (size_t)y * imgW;
+    uint16_t* drow = dst + (size_t)y * row_stride;
+    for (int x = imgW + x0; x < imgW + gap; x += 64) drow[x] = 0;     // zero separator columns (wide layout)
     for (int x = x0; x < imgW; x += 64) {
         const int xs = x < d.fw ? x : d.fw - 1;
         int v;
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
 
 hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
                         int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
-                        int stage_mask, hipStream_t s) {
+                        int stage_mask, hipStream_t s, int wide_row_stride, int gap) {
     if (count <= 0) return hipSuccess;
     if (stage_mask & 1) {
         if (any_warp) hipLaunchKernelGGL(crop_warp_kernel, dim3(16, count), dim3(256), 0, s, gray, H, W, descs_dev, first, wscratch);
@@ -219,7 +224,12 @@ hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs
     }
     if (stage_mask & 2) {
         if (any_tall) hipLaunchKernelGGL(crop_pil_h_kernel, dim3(8, count), dim3(256), 0, s, descs_dev, first, scratch, luts, hscratch);
-        hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, imgW);
+        if (wide_row_stride > 0)
+            hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket,
+                               wide_row_stride, 1LL, gap);
+        else
+            hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, imgW,
+                               (long long)64 * imgW, 0);
     }
     return hipGetLastError();
 }
@@ -308,5 +318,55 @@ hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int 
     if (total == 0) return hipSuccess;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(rowmean3_kernel, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ wide recogniser image helpers
+// All crops of a recognition pass sit side by side in ONE image (crop_final's wide layout), so every CRNN layer is one launch
+// over [H, Wt] instead of one per width bucket.  The columns between two crops are that layer's zero padding: a conv writes
+// neighbour-dependent values there, so they are cleared again on every layer's output (a few columns per crop).
+// shift: log2 of the layer's horizontal down-scale (1 after conv0's pool, 2 after r1's), gapw = 4 >> shift columns.
+__global__ void __launch_bounds__(256) crnn_zero_gaps_kernel(uint16_t* __restrict__ t, const CropDesc* __restrict__ descs, int first, int H, int Wl,
+                                                             int C8, int shift, int gapw) {
+    const CropDesc d = descs[first + blockIdx.x];
+    const int x0 = (d.slot + d.imgW) >> shift;
+    const int total = H * gapw * C8;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c8 = i % C8, r = i / C8;
+        const int gx = r % gapw, y = r / gapw;
+        if (x0 + gx < Wl) *(u32x4*)(t + ((size_t)y * Wl + x0 + gx) * C8 * 8 + (size_t)c8 * 8) = (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+hipError_t launch_crnn_zero_gaps(uint16_t* t, const CropDesc* descs_dev, int first, int count, int H, int Wl, int C, int shift, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(crnn_zero_gaps_kernel, dim3(count), dim3(256), 0, s, t, descs_dev, first, H, Wl, C / 8, shift, 4 >> shift);
+    return hipGetLastError();
+}
+
+// AdaptiveAvgPool over the 3 feature rows + gather: wide features [3][Wc][C] -> pooled rows [row0 + t][C] of every crop
+// (columns slot/4 .. slot/4 + T - 1, T = imgW/4 - 1, row0 = CropDesc::pad_)
+__global__ void __launch_bounds__(256) rowmean3_gather_kernel(const uint16_t* __restrict__ in, int Wc, int C8, const CropDesc* __restrict__ descs,
+                                                              int first, uint16_t* __restrict__ out) {
+    const CropDesc d = descs[first + blockIdx.y];
+    const int T = d.imgW / 4 - 1, xs = d.slot >> 2;
+    const size_t plane = (size_t)Wc * C8 * 8;
+    const int total = T * C8;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int t = i / C8, c8 = i - t * C8;
+        const uint16_t* p = in + ((size_t)(xs + t) * C8 + c8) * 8;
+        const u32x4 a = *(const u32x4*)(p), bq = *(const u32x4*)(p + plane), c = *(const u32x4*)(p + 2 * plane);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = (__uint_as_float(a[j] << 16) + __uint_as_float(bq[j] << 16) + __uint_as_float(c[j] << 16)) / 3.0f;
+            const float hi = (__uint_as_float(a[j] & 0xffff0000u) + __uint_as_float(bq[j] & 0xffff0000u) + __uint_as_float(c[j] & 0xffff0000u)) / 3.0f;
+            o[j] = pack_bf16x2(lo, hi);
+        }
+        *(u32x4*)(out + ((size_t)(d.pad_ + t) * C8 + c8) * 8) = o;
+    }
+}
+hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rowmean3_gather_kernel, dim3(8, count), dim3(256), 0, s, in, Wc, C / 8, descs_dev, first, out);
     return hipGetLastError();
 }

@@ -87,16 +87,20 @@ struct CropDesc {      // one recogniser input, filled on the host
     int warp_off;      // byte offset of the warped crop in the warp scratch
     int a_off;         // byte offset of the stage-A (cv2-resized) crop in the crop scratch
     int lut_off;       // >= 0: contrast LUT (256 bytes) offset, -1: none
-    int pad_;
+    int pad_;          // wide recogniser image: first pooled row (time step) of this crop in the sequence tensors
     double Minv[9];    // dst -> src homography (already inverted)
 };
 // stage_mask bit0: gather (warp) + cv2 resize into scratch; bit1: (PIL bicubic) + LUT + normalise + pad into out_bucket
 hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
                         int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
-                        int stage_mask, hipStream_t s);
+                        int stage_mask, hipStream_t s, int wide_row_stride = 0, int gap = 0);   // wide_row_stride > 0: ONE image [64][Wt], slot = first column
 hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, int first, int count, unsigned int* hist, hipStream_t s);
 hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, hipStream_t s);
 hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s);
+// wide recogniser image (all crops side by side, CropDesc::slot = first column, ::pad_ = first pooled row): clear the separator
+// columns of a layer output [H][Wl][C] (shift = log2 horizontal down-scale), and the 3-row mean gathered into the pooled rows
+hipError_t launch_crnn_zero_gaps(uint16_t* t, const CropDesc* descs_dev, int first, int count, int H, int Wl, int C, int shift, hipStream_t s);
+hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, hipStream_t s);
 // BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
 // tiles_dev: int4 per workgroup {first row, sequences (<=16), T, 0}; tensors are pooled over all buckets: [rows, C]
 hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s);
