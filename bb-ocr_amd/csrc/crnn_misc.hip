@@ -261,27 +261,33 @@ __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restr
                 v[dy][dx] = (iy >= 0 && iy < 64 && ix >= 0 && ix < W) ? bf16_bits_to_f32(p[(size_t)iy * W + ix]) : 0.f;
             }
         uint16_t* op = out + i * 32;
-#pragma unroll 4
-        for (int c = 0; c < 32; c += 2) {
-            float m[2];
+#pragma unroll 1
+        for (int c8 = 0; c8 < 32; c8 += 8) {        // 8 channels -> one 16-byte store (4-byte stores made this kernel store-issue bound)
+            u32x4 o;
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const float* wc = w + (c + cc) * 9;
-                float best = 0.f;   // ReLU floor
+            for (int c2 = 0; c2 < 4; ++c2) {
+                float m[2];
 #pragma unroll
-                for (int py = 0; py < 2; ++py)
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = c8 + c2 * 2 + cc;
+                    const float* wc = w + c * 9;
+                    float best = 0.f;   // ReLU floor
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        float a = b[c + cc];
+                    for (int py = 0; py < 2; ++py)
 #pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
+                        for (int px = 0; px < 2; ++px) {
+                            float a = b[c];
 #pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) a = fmaf(wc[ky * 3 + kx], v[py + ky][px + kx], a);
-                        best = fmaxf(best, a);
-                    }
-                m[cc] = best;
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx) a = fmaf(wc[ky * 3 + kx], v[py + ky][px + kx], a);
+                            best = fmaxf(best, a);
+                        }
+                    m[cc] = best;
+                }
+                o[c2] = pack_bf16x2(m[0], m[1]);
             }
-            *(unsigned int*)(op + c) = pack_bf16x2(m[0], m[1]);
+            *(u32x4*)(op + c8) = o;
         }
     }
 }
