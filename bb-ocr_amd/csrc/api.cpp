@@ -113,7 +113,7 @@ struct bbocr_ctx {
     uint16_t* cls_tail_frag = nullptr;   // conv_cls.6 weight as an MFMA A fragment
     // ---- recogniser
     bool crnn_loaded = false;
-    float* r0_wb = nullptr;      // w[32*9] b[32]
+    float* r0_wb = nullptr;      // w[9][32] (tap-major) b[32]
     ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
     uint16_t* whh[2] = {nullptr, nullptr};
     std::vector<void*> owned;    // every hipMalloc'd weight block
@@ -293,7 +293,8 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         std::vector<float> t(32 * 9 + 32);
         const float* w = tm.get(fe + "0.weight", 32 * 9);
         const float* b = tm.get(fe + "0.bias", 32);
-        std::copy(w, w + 288, t.begin());
+        for (int co = 0; co < 32; ++co)                       // tap-major [9][32]: the kernel reads channel PAIRS of one tap (packed FMA)
+            for (int tap = 0; tap < 9; ++tap) t[tap * 32 + co] = w[co * 9 + tap];
         std::copy(b, b + 32, t.begin() + 288);
         c->r0_wb = upload(c, t);
     }

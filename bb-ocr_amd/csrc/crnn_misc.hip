@@ -262,30 +262,32 @@ __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restr
             }
         uint16_t* op = out + i * 32;
 #pragma unroll 1
-        for (int c8 = 0; c8 < 32; c8 += 8) {        // 8 channels -> one 16-byte store (4-byte stores made this kernel store-issue bound)
+        for (int c8 = 0; c8 < 32; c8 += 8) {        // 8 channels -> one 16-byte store
             u32x4 o;
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
-                float m[2];
+                // two channels at a time on the packed fp32 pipe (v_pk_fma_f32): w is tap-major [9][32], so a channel pair of
+                // one tap is one 8-byte scalar load and the input value is broadcast to both halves.  (Keeping all 64 pair
+                // accumulators live with tap-outer loops and LDS-broadcast weights was measured 1.6x SLOWER.)
+                const int c = c8 + c2 * 2;
+                const f32x2_t bias = {b[c], b[c + 1]};
+                f32x2_t best = {0.f, 0.f};   // ReLU floor
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const int c = c8 + c2 * 2 + cc;
-                    const float* wc = w + c * 9;
-                    float best = 0.f;   // ReLU floor
+                for (int py = 0; py < 2; ++py)
 #pragma unroll
-                    for (int py = 0; py < 2; ++py)
+                    for (int px = 0; px < 2; ++px) {
+                        f32x2_t a = bias;
 #pragma unroll
-                        for (int px = 0; px < 2; ++px) {
-                            float a = b[c];
+                        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                                for (int kx = 0; kx < 3; ++kx) a = fmaf(wc[ky * 3 + kx], v[py + ky][px + kx], a);
-                            best = fmaxf(best, a);
-                        }
-                    m[cc] = best;
-                }
-                o[c2] = pack_bf16x2(m[0], m[1]);
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const f32x2_t wv = *(const f32x2_t*)(w + (ky * 3 + kx) * 32 + c);
+                                const float x = v[py + ky][px + kx];
+                                a = __builtin_elementwise_fma(wv, (f32x2_t){x, x}, a);
+                            }
+                        best = __builtin_elementwise_max(best, a);
+                    }
+                o[c2] = pack_bf16x2(best[0], best[1]);
             }
             *(u32x4*)(op + c8) = o;
         }
