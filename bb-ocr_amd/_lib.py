@@ -92,6 +92,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the MI355X backend has no CPU fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+    # torch wheels bundle their own libamdhip64; libbbocr.so needs the same SONAME.  Whichever is loaded first serves both, and a
+    # process with TWO HIP runtimes cannot create streams (bbocr_create fails): load torch's first so that there is only one.
+    try:
+        import torch  # noqa: F401
+    except Exception:       # a torch-free host still gets the ABI (system ROCm runtime)
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:
