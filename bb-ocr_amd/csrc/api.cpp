@@ -81,6 +81,7 @@ struct bbocr_ctx {
     hipStream_t stream = nullptr;
     DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
     unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
+    int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
     hipStream_t cur = nullptr;                // stream the layer helpers launch on
     hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
     std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
@@ -123,7 +124,7 @@ struct bbocr_ctx {
     DevBuf heat, gray, resized;
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
     DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
-    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out;
+    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs;
     DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
 
@@ -315,7 +316,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
             const float* bhh = tm.get(sm + "rnn.bias_hh_l0" + sfx, 1024);
             for (int g = 0; g < 4; ++g)
                 for (int u = 0; u < 256; ++u) {
-                    const int src = g * 256 + u, dst = lstm_variant() == 8 ? lstm8_xproj_channel(d, g, u) : lstm_xproj_channel(d, g, u);
+                    const int src = g * 256 + u, dst = lstm8_xproj_channel(d, g, u);
                     std::copy(wih + (size_t)src * 256, wih + (size_t)src * 256 + 256, w.begin() + (size_t)dst * 256);
                     b[dst] = bih[src] + bhh[src];
                 }
@@ -325,8 +326,7 @@ static void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         const float* hf = tm.get(sm + "rnn.weight_hh_l0", (size_t)1024 * 256);
         const float* hb = tm.get(sm + "rnn.weight_hh_l0_reverse", (size_t)1024 * 256);
         std::vector<uint16_t> pk(lstm_whh_packed_elems());
-        if (lstm_variant() == 8) pack_lstm_whh8(hf, hb, pk.data());
-        else pack_lstm_whh(hf, hb, pk.data());
+        pack_lstm_whh8(hf, hb, pk.data());
         c->whh[l] = upload(c, pk);
         std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
         std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);
@@ -948,17 +948,24 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
         c->ctc_pmax.ensure(rows * 4);
         c->ctc_out_idx.ensure(rows * 4);
         c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
+        const bool beam = c->beam_width > 0;
+        if (beam) c->ctc_probs.ensure(rows * 112 * sizeof(float));
         HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
-                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask));
+                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
         std::vector<int> oidx(rows);
         std::vector<CtcOut> oo(nseq);
+        std::vector<float> probs(beam ? rows * 112 : 0);
+        std::vector<std::vector<int>> beam_texts;
         HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
         for (int i = 0; i < nseq; ++i) {
             const int k = seq_k[i];
             const size_t r0 = (size_t)seqs[2 * i];
-            texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
+            if (beam) texts[k] = beam_texts[i];
+            else texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
             // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
             confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
         }
@@ -993,6 +1000,9 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
     if (!c->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
     if (p.ignore_mask[0] & 1u) fail(BBOCR_ERR_ARG, "the CTC blank (class 0) cannot be ignored");
     for (int i = 0; i < 4; ++i) c->ignore_mask[i] = p.ignore_mask[i];
+    if (p.decoder != BBOCR_DECODER_GREEDY && p.decoder != BBOCR_DECODER_BEAMSEARCH) fail(BBOCR_ERR_ARG, "unknown decoder");
+    if (p.decoder == BBOCR_DECODER_BEAMSEARCH && p.beam_width <= 0) fail(BBOCR_ERR_ARG, "beam_width must be positive");
+    c->beam_width = p.decoder == BBOCR_DECODER_BEAMSEARCH ? p.beam_width : 0;
     jobs.clear();
     box_off.assign(B + 1, 0);
     for (int b = 0; b < B; ++b) {
@@ -1311,6 +1321,7 @@ void bbocr_default_params(bbocr_params* p) {
     p->text_threshold = 0.7; p->low_text = 0.4; p->link_threshold = 0.4; p->canvas_size = 2560; p->mag_ratio = 1.0;
     p->slope_ths = 0.1; p->ycenter_ths = 0.5; p->height_ths = 0.5; p->width_ths = 0.5; p->add_margin = 0.1; p->min_size = 20;
     p->contrast_ths = 0.1; p->adjust_contrast = 0.5;
+    p->decoder = BBOCR_DECODER_GREEDY; p->beam_width = 5;
 }
 
 int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
@@ -1625,6 +1636,25 @@ int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr
     return BBOCR_OK;
 }
 
+int bbocr_host_ctc_beam(const float* probs, int n, int T, int C, int cs, int beam_width, int* text_off, int* text_idx) {
+    if (!probs || !text_off || !text_idx || n <= 0 || T <= 0 || C <= 0 || C > cs || beam_width <= 0) return BBOCR_ERR_ARG;
+    try {
+        std::vector<int> seqs;
+        for (int i = 0; i < n; ++i) { seqs.push_back(i * T); seqs.push_back(T); }
+        std::vector<std::vector<int>> texts;
+        ctc_beam_search_batch(probs, seqs.data(), n, C, cs, beam_width, texts);
+        int o = 0;
+        for (int i = 0; i < n; ++i) {
+            text_off[i] = o;
+            for (int v : texts[i]) text_idx[o++] = v;
+        }
+        text_off[n] = o;
+    } catch (...) {
+        return BBOCR_ERR_INTERNAL;
+    }
+    return BBOCR_OK;
+}
+
 // ---------------------------------------------------------------------------------------- single-operator entry points
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, int KH,
                     int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
@@ -1679,9 +1709,10 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
 }
 
 int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf,
-                 const unsigned int* ignore_mask) {
+                 const unsigned int* ignore_mask, int beam_width) {
     return guarded(ctx, [&] {
         if (!dev_logits || !text_off || !text_idx || !conf || n <= 0 || T <= 0 || C <= 0 || C > cs) fail(BBOCR_ERR_ARG, "bad ctc arguments");
+        const bool beam = beam_width > 0;
         const size_t rows = (size_t)n * T;
         ctx->ctc_idx.ensure(rows * 4);
         ctx->ctc_pmax.ensure(rows * 4);
@@ -1691,17 +1722,23 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
         for (int i = 0; i < n; ++i) { seqs.push_back(i * T); seqs.push_back(T); }
         ctx->seq_tables.ensure(seqs.size() * 4);
         HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (beam) ctx->ctc_probs.ensure(rows * cs * sizeof(float));
         HIPCHK(launch_ctc(dev_logits, rows, C, cs, (const int*)ctx->seq_tables.p, n, (int*)ctx->ctc_idx.p, (float*)ctx->ctc_pmax.p,
-                          (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p, ctx->stream, ignore_mask));
+                          (int*)ctx->ctc_out_idx.p, (CtcOut*)ctx->ctc_out.p, ctx->stream, ignore_mask, beam ? (float*)ctx->ctc_probs.p : nullptr));
         std::vector<int> oidx(rows);
         std::vector<CtcOut> oo(n);
+        std::vector<float> probs(beam ? rows * cs : 0);
+        std::vector<std::vector<int>> beam_texts;
         HIPCHK(hipMemcpyAsync(oidx.data(), ctx->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(oo.data(), ctx->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, ctx->stream));
+        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), ctx->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), n, C, cs, beam_width, beam_texts);
         int o = 0;
         for (int i = 0; i < n; ++i) {
             text_off[i] = o;
-            for (int k = 0; k < oo[i].len; ++k) text_idx[o++] = oidx[(size_t)i * T + k];
+            if (beam) for (int v : beam_texts[i]) text_idx[o++] = v;
+            else for (int k = 0; k < oo[i].len; ++k) text_idx[o++] = oidx[(size_t)i * T + k];
             conf[i] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
         }
         text_off[n] = o;

@@ -278,15 +278,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
     else pooled(std::integral_constant<int, 4>{});
 }
 
-// 512-thread configs run one workgroup per CU (2 waves/SIMD inside it); 256-thread configs are built for TWO co-resident
+// Generic register-staged variant (any kernel size / dilation / pooling): 256-thread workgroups built for TWO co-resident
 // workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
-template <int WM, int WN, int MF, int PITER, int RING>
+template <int WM, int WN, int MF, int PITER>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     constexpr int WBUF = BN * 64;          // bytes of one weight k-step slice (BN couts x 32 k x 2 B)
     constexpr int WPIECES = WBUF / 16;     // 16-B pieces per slice
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WRING = RING;
+    constexpr int WRING = 2;               // weight k-step slices in flight
     unsigned char* const wbuf = smem;                  // [WRING][WBUF]
     unsigned char* const pbuf = smem + WRING * WBUF;   // [2][NP*64]
     const int patch_bytes = a.NP * 64;
@@ -337,24 +337,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
         const uint16_t* src = s0 ? a.in0 : a.in1;
         const int cs = s0 ? a.in0_cs : a.in1_cs;
         const int cb = (s0 ? c : c - a.C0) + l_kg * 8;
-        int issued = 0;
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
             const int sp = src_pix[part * PH + i];
-            if constexpr (RING == 2) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (sp >= 0 && !(a.dbg & 2)) v = *(const u32x4*)(src + (size_t)sp * cs + cb);   // dbg bit 2: timing-only ablation
-                pre[i] = v;
-            } else {
-                // counted-wait schedule: the number of loads a wave ISSUES must be known exactly (vmcnt bookkeeping): the
-                // wave-uniform guard below is the only condition; out-of-image lanes read pixel 0 and are zeroed at store time
-                if (wave + (part * PH + i) * NW < n_wi) {
-                    pre[i] = *(const u32x4*)(src + (size_t)(sp >= 0 ? sp : 0) * cs + cb);
-                    ++issued;
-                }
-            }
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (sp >= 0 && !(a.dbg & 2)) v = *(const u32x4*)(src + (size_t)sp * cs + cb);   // dbg bit 2: timing-only ablation
+            pre[i] = v;
         }
-        return issued;
     };
     auto store_part = [&](int chunk, auto part_c) {
         constexpr int part = decltype(part_c)::value;
@@ -365,7 +354,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
             const int wi = wave + (part * PH + i) * NW;
             if (wi < n_wi) {
                 u32x4 v = pre[i];
-                if (RING != 2 && src_pix[part * PH + i] < 0) v = (u32x4){0u, 0u, 0u, 0u};
                 if (relu) {
                     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
@@ -430,8 +418,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (RING == 2) {
-        // reference schedule: 2-deep weight ring, fragments read at the top of every k-step
+    {
+        // 2-deep weight ring, fragments read at the top of every k-step
         issue_w(0, 0);
         stage_patch_now(0);
         __syncthreads();
@@ -466,105 +454,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
                     if (a.ntaps >= 3) stage_patch_store(c + 1, tap);
                     else if (tap == a.ntaps - 1) store_part(c + 1, P0{});
                 }
-                if (a.dbg & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // dbg bit 8: asm form of the barrier
-                else __syncthreads();
+                __syncthreads();
                 if (++kx == a.KW) { kx = 0; ++ky; }
-            }
-        }
-    } else {
-        // deep-ring counted-wait schedule (256-thread configs: every wave issues WPT weight DMAs per slice).
-        // Weight slice ks+RING-1 is issued at k-step ks, FIRST among the k-step's VMEM operations; the next chunk's
-        // activation loads follow it.  vmcnt retires in order, so the barrier at the end of k-step ks only has to make
-        // slice ks+1 (issued RING-2 k-steps ago) visible: it waits with a COUNTED vmcnt that leaves every younger
-        // operation in flight -- RING-2 k-steps of weight DMA and activation loads ride across the barriers, which
-        // gives an HBM-latency activation load up to RING k-steps before anything has to wait for it.
-        constexpr int WPT = WPIECES / NT;
-        static_assert(WPIECES % NT == 0 && RING >= 3 && RING <= 4, "counted schedule needs uniform DMA issue");
-        constexpr int NMAX = PH + (RING - 2) * (WPT + PH);
-        auto wait_vm_barrier = [&](int nvm) {      // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
-#define BBOCR_WVM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-            switch (nvm) {
-                BBOCR_WVM(0) BBOCR_WVM(1) BBOCR_WVM(2) BBOCR_WVM(3) BBOCR_WVM(4) BBOCR_WVM(5) BBOCR_WVM(6) BBOCR_WVM(7) BBOCR_WVM(8)
-                BBOCR_WVM(9) BBOCR_WVM(10) BBOCR_WVM(11) BBOCR_WVM(12) BBOCR_WVM(13) BBOCR_WVM(14) BBOCR_WVM(15) BBOCR_WVM(16)
-                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-            }
-#undef BBOCR_WVM
-        };
-        static_assert(NMAX <= 16, "extend the vmcnt dispatch table");
-#pragma unroll
-        for (int i = 0; i < RING - 1; ++i)
-            if (i < nk) issue_w(i, i);
-        stage_patch_now(0);
-        __syncthreads();
-        // VMEM operations issued in k-steps ks-2, ks-1 (hw/hp: weight DMAs / activation loads still unconsumed)
-        int hw1 = 0, hp1 = 0, hp2 = 0;
-        int ks = 0, wslot = 0;
-        for (int c = 0; c < a.nchunks; ++c) {
-            const bool more = (c + 1 < a.nchunks);
-            const unsigned char* pbase = pbuf + (c & 1) * patch_bytes + lane_patch_off;
-            int ky = 0, kx = 0;
-            for (int tap = 0; tap < a.ntaps; ++tap, ++ks) {
-                int w_now = 0, p_now = 0;
-                if (ks + RING - 1 < nk) {
-                    int slot = wslot + RING - 1;
-                    if (slot >= RING) slot -= RING;
-                    issue_w(ks + RING - 1, slot);
-                    w_now = WPT;
-                }
-                if (more) {
-                    if (a.ntaps >= 3) {
-                        if (tap == 0) p_now = load_part(c + 1, P0{});
-                        if constexpr (NPART > 1) { if (tap == S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); }
-                        if constexpr (NPART > 2) { if (tap == 2 * S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); }
-                        if constexpr (NPART > 3) { if (tap == 3 * S) p_now = load_part(c + 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); }
-                    } else if (tap == 0) {
-                        p_now = load_part(c + 1, P0{});
-                    }
-                }
-                const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
-                bf16x8 af[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
-                const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
-                bf16x8 bq[MF];
-#pragma unroll
-                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
-#pragma unroll
-                for (int f = 0; f < MF; ++f) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF, 0);
-                // stores: hipcc waits for the stored part's loads by itself; that part then no longer counts as in flight
-                if (more) {
-                    bool stored = false;
-                    int age = 0;   // k-steps since the stored part was loaded
-                    if (a.ntaps >= 3) {
-                        if (tap == S - 1) { store_part(c + 1, P0{}); stored = true; age = S - 1; }
-                        if constexpr (NPART > 1) { if (tap == 2 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 1 ? 1 : 0)>{}); stored = true; age = S - 1; } }
-                        if constexpr (NPART > 2) { if (tap == 3 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 2 ? 2 : 0)>{}); stored = true; age = S - 1; } }
-                        if constexpr (NPART > 3) { if (tap == 4 * S - 1) { store_part(c + 1, std::integral_constant<int, (NPART > 3 ? 3 : 0)>{}); stored = true; age = S - 1; } }
-                    } else if (tap == a.ntaps - 1) {
-                        store_part(c + 1, P0{});
-                        stored = true;
-                        age = a.ntaps - 1;
-                    }
-                    if (stored) {
-                        if (age == 0) p_now = 0;
-                        else if (age == 1) hp1 = 0;
-                        else if (age == 2) hp2 = 0;
-                    }
-                }
-                // operations younger than slice ks+1 (issued first in k-step ks-(RING-2)): what that k-step issued after
-                // it, plus everything of the k-steps since
-                int nvm;
-                if constexpr (RING == 3) nvm = hp1 + w_now + p_now;
-                else nvm = hp2 + hw1 + hp1 + w_now + p_now;
-                wait_vm_barrier((a.dbg & 4) ? 0 : nvm);   // dbg bit 4: drain everything (A/B of the counted wait itself)
-                hp2 = hp1; hp1 = p_now; hw1 = w_now;
-                if (++kx == a.KW) { kx = 0; ++ky; }
-                wslot = wslot + 1 == RING ? 0 : wslot + 1;
             }
         }
     }
@@ -999,9 +890,9 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
                 }
 }
 
-template <int WM, int WN, int MF, int PITER, int RING>
+template <int WM, int WN, int MF, int PITER>
 static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
-    auto k = conv_mfma_kernel<WM, WN, MF, PITER, RING>;
+    auto k = conv_mfma_kernel<WM, WN, MF, PITER>;
     static size_t cur = 0;   // per-instantiation high-water mark of the opt-in dynamic LDS size
     if (smem > cur) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1012,24 +903,11 @@ static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream
     return hipGetLastError();
 }
 
-static int conv_ring() {   // generic kernel: BBOCR_CONV_RING=3/4 selects the counted deep-ring schedule (A/B runs; measured slower
-                           // than the reference schedule because register-staged loads still drain at every store)
-    static const int v = [] { const char* e = getenv("BBOCR_CONV_RING"); const int r = e ? atoi(e) : 2; return r < 2 ? 2 : (r > 4 ? 4 : r); }();
-    return v;
-}
-
 template <int WM, int WN, int MF, int PITER>
 static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
-    constexpr int BNc = WN * 64;
-    const size_t patch = (size_t)2 * a.NP * 64;
-    if constexpr (WM * WN == 4) {   // 256-thread configs: counted schedule, deepest ring that still lets two workgroups share a CU
-        const int want = conv_ring();
-        if (want >= 4 && (size_t)4 * BNc * 64 + patch <= 80 * 1024) return launch_one<WM, WN, MF, PITER, 4>(a, (size_t)4 * BNc * 64 + patch, grid, s);
-        if (want >= 3 && (size_t)3 * BNc * 64 + patch <= 80 * 1024) return launch_one<WM, WN, MF, PITER, 3>(a, (size_t)3 * BNc * 64 + patch, grid, s);
-    }
-    const size_t smem = (size_t)2 * BNc * 64 + patch;
+    const size_t smem = (size_t)2 * WN * 64 * 64 + (size_t)2 * a.NP * 64;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    return launch_one<WM, WN, MF, PITER, 2>(a, smem, grid, s);
+    return launch_one<WM, WN, MF, PITER>(a, smem, grid, s);
 }
 
 static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 variant (A/B runs)
@@ -1100,29 +978,22 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-static bool conv_small_wg() {   // BBOCR_CONV_WG=512 selects the original one-workgroup-per-CU configurations (A/B runs)
-    static const bool v = [] { const char* e = getenv("BBOCR_CONV_WG"); return !(e && atoi(e) == 512); }();
-    return v;
-}
-
-int conv_plan_bn(int Cout) {
-    static const int bn64_upto = [] { const char* e = getenv("BBOCR_BN64_UPTO"); return e ? atoi(e) : 64; }();   // A/B knob
-    if (conv_small_wg()) return Cout > bn64_upto ? 128 : 64;
-    return Cout >= 256 ? 256 : (Cout > 64 ? 128 : 64);
+int conv_plan_bn(int Cout) {   // couts per workgroup tile (BBOCR_BN64_UPTO: A/B knob, measured no gain for the 128-cout layers)
+    static const int bn64_upto = [] { const char* e = getenv("BBOCR_BN64_UPTO"); return e ? atoi(e) : 64; }();
+    return Cout > bn64_upto ? 128 : 64;
 }
 
 hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const int BN = p.BN;
-    const bool small = conv_small_wg();
-    const int NWV = small ? 4 : 8;                                  // waves per workgroup
-    const int BM = small ? 256 : ((BN == 256) ? 256 : 512);
+    constexpr int NWV = 4;       // waves per workgroup
+    constexpr int BM = 256;      // output pixels per workgroup tile
     a.KH = p.KH; a.KW = p.KW; a.pad_h = p.pad_h; a.pad_w = p.pad_w; a.dil = p.dil;
     a.OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil;
     a.OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
     a.sub = 1;
-    if (small && conv_dma() && a.zero && !a.pool_mode && p.KH == 3 && p.KW == 3 && p.dil > 1 && p.pad_h == p.dil && p.pad_w == p.dil) {
+    if (conv_dma() && a.zero && !a.pool_mode && p.KH == 3 && p.KW == 3 && p.dil > 1 && p.pad_h == p.dil && p.pad_w == p.dil) {
         const int d = p.dil, LH = cdiv(a.OH, d), LW = cdiv(a.OW, d);   // phase sub-lattice size
         long long best = -1;
         for (int th = 16; th >= 4; th >>= 1) {
@@ -1155,7 +1026,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
         }
     }
     const int ring = 2;
-    const int max_piter = small ? 16 : 8;
+    const int max_piter = 16;
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
     {
         long long best = -1;
@@ -1166,7 +1037,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             const int pit = cdiv(np / 16, NWV), pit_r = pit <= 4 ? 4 : (pit <= 8 ? 8 : 16), nparts = pit_r / 4;
             if (pit > max_piter || (size_t)ring * BN * 64 + (size_t)2 * np * 64 > 160 * 1024) continue;
             if (a.ntaps >= 3 ? (a.ntaps - 1) / nparts < 1 : nparts > 1) continue;
-            if (a.pool_mode && (small ? (BN == 128 ? 8 : 4) : (BN == 64 ? 4 : 8)) % (2 * (tw / 16)) != 0) continue;
+            if (a.pool_mode && (BN == 128 ? 8 : 4) % (2 * (tw / 16)) != 0) continue;
             const long long tiles = (long long)cdiv(a.OH, th) * cdiv(a.OW, tw);
             const long long cost = tiles * ((long long)BM * a.ntaps + 2LL * np);
             if (best < 0 || cost < best) { best = cost; a.TH = th; a.TW = tw; a.PH = ph; a.PW = pw; a.NP = np; }
@@ -1186,12 +1057,12 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
-    if (a.addup && !(small && conv_dma() && p.KH == 1 && p.KW == 1 && a.zero && !a.pool_mode && !a.out_f32 && !a.tail && a.cout_store % 64 == 0 &&
+    if (a.addup && !(conv_dma() && p.KH == 1 && p.KW == 1 && a.zero && !a.pool_mode && !a.out_f32 && !a.tail && a.cout_store % 64 == 0 &&
                      a.cout_store == p.Cout_pad))
         return hipErrorInvalidValue;
-    if (small && conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
+    if (conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
         return BN == 128 ? launch_dma1x1<2, 2, 8>(a, s) : launch_dma1x1<4, 1, 4>(a, s);
-    if (small && conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
+    if (conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
         const int npb = cdiv(a.PH * a.PW, 64);
         if (npb == 6 || npb == 7) {
             a.NP = npb * 64;
@@ -1199,13 +1070,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
         }
     }
     const int piter = cdiv(a.NP / 16, NWV);
-    if (small) {
-        if (BN == 128) return piter <= 4 ? launch_cfg<2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<2, 2, 8, 8>(a, grid, s) : launch_cfg<2, 2, 8, 16>(a, grid, s));
-        if (BN == 64) return piter <= 4 ? launch_cfg<4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<4, 1, 4, 8>(a, grid, s) : launch_cfg<4, 1, 4, 16>(a, grid, s));
-        return hipErrorInvalidValue;
-    }
-    if (BN == 256) return piter <= 4 ? launch_cfg<2, 4, 8, 4>(a, grid, s) : launch_cfg<2, 4, 8, 8>(a, grid, s);
-    if (BN == 128) return piter <= 4 ? launch_cfg<4, 2, 8, 4>(a, grid, s) : launch_cfg<4, 2, 8, 8>(a, grid, s);
-    if (BN == 64) return piter <= 4 ? launch_cfg<8, 1, 4, 4>(a, grid, s) : launch_cfg<8, 1, 4, 8>(a, grid, s);
+    if (BN == 128) return piter <= 4 ? launch_cfg<2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<2, 2, 8, 8>(a, grid, s) : launch_cfg<2, 2, 8, 16>(a, grid, s));
+    if (BN == 64) return piter <= 4 ? launch_cfg<4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<4, 1, 4, 8>(a, grid, s) : launch_cfg<4, 1, 4, 16>(a, grid, s));
     return hipErrorInvalidValue;
 }

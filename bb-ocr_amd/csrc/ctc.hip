@@ -11,7 +11,7 @@
 // ignore: recognizer_predict's ignore_idx (allowlist / blocklist) as a 128-bit class mask: `preds_prob[:, :, ignore_idx] = 0`, then
 // the division by the remaining sum that upstream always performs
 __global__ void __launch_bounds__(256) ctc_rows_kernel(const float* __restrict__ logits, size_t rows, int C, int cs, int* __restrict__ idx,
-                                                       float* __restrict__ pmax, uint4 ignore) {
+                                                       float* __restrict__ pmax, uint4 ignore, float* __restrict__ probs) {
     const int lane = threadIdx.x & 63;
     const size_t wave0 = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * 256) >> 6;
@@ -36,6 +36,10 @@ __global__ void __launch_bounds__(256) ctc_rows_kernel(const float* __restrict__
         for (int o = 32; o > 0; o >>= 1) norm += __shfl_xor(norm, o);
         q0 = q0 / norm;
         q1 = q1 / norm;
+        if (probs) {   // decoder='beamsearch': the host search reads the whole distribution (row stride cs)
+            if (lane < C) probs[row * cs + lane] = q0;
+            if (lane + 64 < C) probs[row * cs + lane + 64] = q1;
+        }
         // arg-max over probabilities, first index wins ties (numpy argmax)
         float bp = q0;
         int bi = lane;
@@ -94,13 +98,13 @@ __global__ void __launch_bounds__(64) ctc_collapse_kernel(const int* __restrict_
 }
 
 hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,
-                      int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore) {
+                      int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore, float* probs_out) {
     if (nseq <= 0 || rows == 0) return hipSuccess;
     if (C > 128) return hipErrorInvalidValue;
     const size_t blocks = (rows + 3) / 4;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
     hipLaunchKernelGGL(ctc_rows_kernel, dim3(grid), dim3(256), 0, s, logits, rows, C, cs, idx_tmp, pmax_tmp,
-                       make_uint4(ignore ? ignore[0] : 0u, ignore ? ignore[1] : 0u, ignore ? ignore[2] : 0u, ignore ? ignore[3] : 0u));
+                       make_uint4(ignore ? ignore[0] : 0u, ignore ? ignore[1] : 0u, ignore ? ignore[2] : 0u, ignore ? ignore[3] : 0u), probs_out);
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(nseq), dim3(64), 0, s, idx_tmp, pmax_tmp, (const int2*)seqs_dev, out_idx, out);
     return hipGetLastError();
 }

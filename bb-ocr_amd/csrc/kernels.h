@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 // ------------------------------------------------------------------ implicit-GEMM convolution (conv_mfma.hip)
 struct ConvArgs {
@@ -101,19 +102,19 @@ hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int 
 // columns of a layer output [H][Wl][C] (shift = log2 horizontal down-scale), and the 3-row mean gathered into the pooled rows
 hipError_t launch_crnn_zero_gaps(uint16_t* t, const CropDesc* descs_dev, int first, int count, int H, int Wl, int C, int shift, hipStream_t s);
 hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, hipStream_t s);
-// BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
+// BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm8_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
 // tiles_dev: int4 per workgroup {first row, sequences (<=16), T, 0}; tensors are pooled over all buckets: [rows, C]
 hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s);
-void pack_lstm_whh(const float* whh_fwd /*[1024][256]*/, const float* whh_bwd, uint16_t* out);
 size_t lstm_whh_packed_elems();
-int lstm_xproj_channel(int dir, int gate, int unit);
-int lstm_variant();   // 8 (default) or 4 waves per workgroup; selects packing + channel permutation
 void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out);
 int lstm8_xproj_channel(int dir, int gate, int unit);
 struct CtcOut { int len; int cnt; float prod; int pad; };
 // seqs_dev: int2 per sequence {first row, T}; logits fp32 [rows, cs]; out_idx is row-indexed like the pool
 hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int* seqs_dev, int nseq, int* idx_tmp, float* pmax_tmp,
-                      int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore = nullptr);   // ignore: 4 x 32-bit class mask or null
+                      int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore = nullptr, float* probs_out = nullptr);   // ignore: 4 x 32-bit class mask or null
+// decoder='beamsearch' (easyocr/utils.py::ctcBeamSearch, host): probs fp32 [rows, cs] as ctc_rows_kernel writes them; seqs = {first row, T}
+void ctc_beam_search_host(const float* mat, int T, int C, int cs, int beam_width, std::vector<int>& text);
+void ctc_beam_search_batch(const float* probs, const int* seqs, int nseq, int C, int cs, int beam_width, std::vector<std::vector<int>>& texts);
 
 // ------------------------------------------------------------------ OCR pre-processing chain (preproc.hip), SURVEY 8 row f2
 hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const short* cx, const int* y0,

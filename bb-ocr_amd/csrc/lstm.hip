@@ -4,10 +4,10 @@
 // easyocr/model/modules.py::BidirectionalLSTM (recogniser SequenceModeling.{0,1}.rnn), reached from
 // reader.readtext (pipeline_demo/extractor/enhanced_extractor.py:520).  The input projection x W_ih^T + b_ih + b_hh
 // is ONE batched GEMM done by conv_mfma (1x1 conv, permuted output channels); this kernel does the T sequential
-// steps.  One workgroup = 16 sequences x one direction, 4 waves; wave w owns hidden units [64w, 64w+64) and all four
-// of their gates, so the gate non-linearity is lane-local:
-//   D[seq][gate col] = h_{t-1}[seq][k] * W_hh^T[k][gate col]   (A = h from LDS, B = W_hh streamed from L2 in fragment order)
-//   fragment (u16, gate): lane l holds unit 64w+16*u16+(l&15) for sequences 4(l>>4)+r.
+// steps.  One workgroup = 16 sequences x one direction, 8 waves (two per SIMD); wave w owns hidden units [32w, 32w+32) and
+// all four of their gates, so the gate non-linearity is lane-local:
+//   D[seq][gate col] = h_{t-1}[seq][k] * W_hh^T[k][gate col]   (A = h from LDS, B = W_hh in fragment order)
+//   fragment (a, gate): lane l holds unit 32w+16*a+(l&15) for sequences 4(l>>4)+r.
 // c stays in fp32 registers for all T steps; h crosses LDS as bf16 (it is the next step's A operand).
 #include "common.h"
 #include "kernels.h"
@@ -17,171 +17,14 @@
 
 size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
 
-// out layout: [dir][wave 4][u16 4][kk 8][gate 4][lane 64][8]  (= MFMA issue order inside a wave)
-void pack_lstm_whh(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
-    size_t o = 0;
-    for (int d = 0; d < 2; ++d) {
-        const float* W = d ? whh_bwd : whh_fwd;
-        for (int w = 0; w < 4; ++w)
-            for (int u16 = 0; u16 < 4; ++u16)
-                for (int kk = 0; kk < 8; ++kk)
-                    for (int gate = 0; gate < 4; ++gate)
-                        for (int l = 0; l < 64; ++l) {
-                            const int unit = w * 64 + u16 * 16 + (l & 15);
-                            const int row = gate * 256 + unit;
-                            for (int j = 0; j < 8; ++j) {
-                                const int k = kk * 32 + 8 * (l >> 4) + j;
-                                out[o++] = f32_to_bf16_host(W[(size_t)row * 256 + k]);
-                            }
-                        }
-    }
-}
-
-// Channel permutation of the input projection so that one lane's 16 gate pre-activations of one sequence are 32
-// contiguous bytes: perm(dir, gate, unit) = dir*1024 + ((unit>>6)*16 + (unit&15))*16 + ((unit>>4)&3)*4 + gate.
-int lstm_xproj_channel(int dir, int gate, int unit) {
-    return dir * 1024 + (((unit >> 6) * 16 + (unit & 15)) * 16) + ((unit >> 4) & 3) * 4 + gate;
-}
-
 // v_exp_f32 + v_rcp_f32 (1 ulp each): 2 transcendental issues per non-linearity instead of an IEEE division sequence
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.442695041f)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390082f)); }
 
 // tiles[b] = {first row of the tile's first sequence in the pooled [rows, C] tensors, sequences in the tile (<= 16), T, -};
 // sequence s of a tile owns rows [row0 + s*T, row0 + (s+1)*T).  Tiles of different buckets (different T) share one launch.
-// W_hh residency: of the 128 weight fragments (1 KiB each) a wave multiplies per step, the first LSTM_NR stay in its
-// registers for all T steps (one wave per SIMD owns the whole 512-entry file), the next LSTM_NL in LDS, and only the
-// rest is re-streamed from L2 every step (512 KiB -> 128 KiB per workgroup and step).
-#define LSTM_NR 64
-#define LSTM_NL 32
-__global__ void __launch_bounds__(256, 1) lstm_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
-                                                      uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
-    unsigned char (*hbuf)[32 * 16 * 16] = (unsigned char (*)[32 * 16 * 16])lstm_smem;   // [2][kgroup 32][seq 16] x 16 B
-    unsigned char* const wlds = lstm_smem + 2 * 32 * 16 * 16;                             // [wave 4][LSTM_NL][lane 64] x 16 B
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y;
-    const int4 tile = tiles[blockIdx.x];
-    const int row0 = tile.x, n = tile.y, T = tile.z;
-    const int g = lane >> 4, u = lane & 15;
-
-    for (int i = tid; i < 2 * 32 * 16 * 16 / 16; i += 256) ((u32x4*)lstm_smem)[i] = (u32x4){0u, 0u, 0u, 0u};
-    float c[4][4];   // [u16][r]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
-    const bf16x8* wv0 = (const bf16x8*)whh + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
-    // fragment fi = (u16*8 + kk)*4 + gate, in MFMA issue order
-    bf16x8 wreg[LSTM_NR];
-#pragma unroll
-    for (int i = 0; i < LSTM_NR; ++i) wreg[i] = wv0[(size_t)i * 64];
-    bf16x8* const wl = (bf16x8*)(wlds + (size_t)wave * LSTM_NL * 1024) + lane;
-#pragma unroll 4
-    for (int i = 0; i < LSTM_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(LSTM_NR + i) * 64];
-    // xproj element offset of this lane's 16 contiguous channels
-    const int xch = dir * 1024 + (wave * 16 + u) * 16;
-    // coalesced h write-back: thread -> (seq, 16-B chunk of the 256 units)
-    const int wb_seq = tid >> 4, wb_kg0 = (tid & 15) * 2;
-    __syncthreads();
-
-    auto load_x = [&](int step, u32x4 (&xq)[4][2]) {
-        const int t = dir ? (T - 1 - step) : step;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = g * 4 + r;
-            if (s < n && step < T) {
-                const uint16_t* xp = xproj + ((size_t)row0 + (size_t)s * T + t) * 2048 + xch;
-                xq[r][0] = *(const u32x4*)(xp);
-                xq[r][1] = *(const u32x4*)(xp + 8);
-            } else {
-                xq[r][0] = (u32x4){0u, 0u, 0u, 0u};
-                xq[r][1] = (u32x4){0u, 0u, 0u, 0u};
-            }
-        }
-    };
-    // gate pre-activations of the input projection (bf16, 4 sequences x 32 B per lane) are fetched one step AHEAD: they
-    // come from HBM, and vmcnt completes in order, so a same-step fetch would put a DRAM latency in front of every
-    // streamed weight fragment.
-    u32x4 xq[4][2], xn[4][2];
-    load_x(0, xq);
-    int cur = 0;
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? (T - 1 - step) : step;
-        load_x(step + 1, xn);
-        const unsigned char* hb = hbuf[cur];
-        unsigned char* hn = hbuf[cur ^ 1];
-        // hiding the pointer keeps hipcc from hoisting the STREAMED fragment loads out of the time loop as well
-        const bf16x8* wv = wv0;
-        asm volatile("" : "+v"(wv));
-        bf16x8 af[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) af[kk] = *(const bf16x8*)(hb + ((kk * 4 + g) * 16 + u) * 16);
-        f32x4 acc[4][4];   // [u16][gate]
-        auto mfma_group = [&](auto a_c) {      // 32 MFMAs: the four gates of 16 hidden units x 16 sequences, K = 256
-            constexpr int a = decltype(a_c)::value;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    constexpr int fi0 = a * 32;
-                    const int fi = fi0 + kk * 4 + q;
-                    bf16x8 bfr;
-                    if (fi < LSTM_NR) bfr = wreg[fi < LSTM_NR ? fi : 0];
-                    else if (fi < LSTM_NR + LSTM_NL) bfr = wl[(size_t)(fi - LSTM_NR) * 64];
-                    else bfr = wv[(size_t)fi * 64];
-                    acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[a][q], 0, 0, 0);
-                }
-        };
-        auto gate_group = [&](auto a_c) {      // lane-local gate math of the same 16 units (4 sequences per lane)
-            constexpr int a = decltype(a_c)::value;
-            const int unit = wave * 64 + a * 16 + u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned int w0 = xq[r][a >> 1][(a & 1) * 2], w1 = xq[r][a >> 1][(a & 1) * 2 + 1];
-                const float gi = acc[a][0][r] + __uint_as_float(w0 << 16);
-                const float gf = acc[a][1][r] + __uint_as_float(w0 & 0xffff0000u);
-                const float gg = acc[a][2][r] + __uint_as_float(w1 << 16);
-                const float go = acc[a][3][r] + __uint_as_float(w1 & 0xffff0000u);
-                const float cn = sigmoid_f(gf) * c[a][r] + sigmoid_f(gi) * tanh_f(gg);
-                c[a][r] = cn;
-                const float hv = sigmoid_f(go) * tanh_f(cn);
-                *(unsigned short*)(hn + ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2) = f32_to_bf16_bits(hv);
-            }
-        };
-        // software pipeline over the four 16-unit groups: the VALU/transcendental gate math of group a runs in the
-        // issue slots the MFMA stream of group a+1 leaves free (an MFMA holds vector issue for half of its 16 cycles)
-        mfma_group(std::integral_constant<int, 0>{});
-        mfma_group(std::integral_constant<int, 1>{});
-        gate_group(std::integral_constant<int, 0>{});
-        mfma_group(std::integral_constant<int, 2>{});
-        gate_group(std::integral_constant<int, 1>{});
-        mfma_group(std::integral_constant<int, 3>{});
-        gate_group(std::integral_constant<int, 2>{});
-        gate_group(std::integral_constant<int, 3>{});
-        __syncthreads();
-        // h_t -> out[seq][t][dir*256 + unit], 32 B per thread
-        {
-            const int s = wb_seq;
-            if (s < n) {
-                const u32x4 h0 = *(const u32x4*)(hn + ((wb_kg0) * 16 + wb_seq) * 16);
-                const u32x4 h1 = *(const u32x4*)(hn + ((wb_kg0 + 1) * 16 + wb_seq) * 16);
-                uint16_t* op = out + ((size_t)row0 + (size_t)s * T + t) * 512 + dir * 256 + wb_kg0 * 8;
-                *(u32x4*)(op) = h0;
-                *(u32x4*)(op + 8) = h1;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { xq[r][0] = xn[r][0]; xq[r][1] = xn[r][1]; }
-        cur ^= 1;
-    }
-}
-
-// ================================================================================================ 8-wave variant
-// Same recurrence, eight waves per workgroup (two per SIMD): wave w owns hidden units [32w, 32w+32) = two 16-unit groups
+//
+// Wave w owns hidden units [32w, 32w+32) = two 16-unit groups
 // x four gates = 64 weight fragments (1 KiB each), one MFMA per fragment and step.  A step is [64 MFMAs][gate math][barrier];
 // what bounds it is latency, so every operand of the MFMA stream is in a register BEFORE its MFMA is due:
 //   visit order v = kk*8 + group*4 + gate (kk = 32-wide slice of h), fragment v lives
@@ -335,31 +178,15 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     }
 }
 
-int lstm_variant() {   // BBOCR_LSTM=4 selects the 4-wave kernel (A/B runs); default: 8-wave kernel
-    static const int v = [] { const char* e = getenv("BBOCR_LSTM"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    return v;
-}
-
 hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
-    if (lstm_variant() == 8) {
-        const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
-        static bool attr8 = false;
-        if (!attr8) {
-            hipError_t e = hipFuncSetAttribute((const void*)lstm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
-            if (e != hipSuccess) return e;
-            attr8 = true;
-        }
-        hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev);
-        return hipGetLastError();
-    }
-    const size_t smem = 2 * 32 * 16 * 16 + (size_t)4 * LSTM_NL * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
+    static bool attr8 = false;
+    if (!attr8) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr8 = true;
     }
-    hipLaunchKernelGGL(lstm_kernel, dim3(ntiles, 2), dim3(256), smem, s, xproj, whh_pk, out, (const int4*)tiles_dev);
+    hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev);
     return hipGetLastError();
 }

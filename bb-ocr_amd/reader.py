@@ -224,6 +224,10 @@ class Reader:
                 setattr(p, k, kw[k])
         for i, w in enumerate(ignore_mask(self.character, self.lang_char, kw.get("allowlist"), kw.get("blocklist"))):
             p.ignore_mask[i] = w
+        decoder = kw.get("decoder", "greedy")
+        self._unsupported(decoder, None, None, None, False, "standard")
+        if decoder == "beamsearch":          # BBOCR_DECODER_BEAMSEARCH
+            p.decoder, p.beam_width = 1, int(kw.get("beamWidth", 5))
         return p
 
     def _to_dev(self, arr):
@@ -305,14 +309,15 @@ class Reader:
         kw = dict(min_size=min_size, contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, text_threshold=text_threshold,
                   low_text=low_text, link_threshold=link_threshold, canvas_size=canvas_size, mag_ratio=mag_ratio, slope_ths=slope_ths,
                   ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail,
-                  allowlist=allowlist, blocklist=blocklist, paragraph=paragraph, x_ths=x_ths, y_ths=y_ths)
+                  allowlist=allowlist, blocklist=blocklist, paragraph=paragraph, x_ths=x_ths, y_ths=y_ths, decoder=decoder,
+                  beamWidth=beamWidth)
         return self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]) if grey is not None else None, **kw)[0]
 
     def readtext_batched(self, image, n_width=None, n_height=None, **kw):
         """List (or 4-D array) of pages -> list of per-page results.  Equal-size pages share one device batch."""
-        self._unsupported(kw.pop("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.pop("rotation_info", None),
+        self._unsupported(kw.get("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.pop("rotation_info", None),
                           kw.get("paragraph", False), kw.pop("output_format", "standard"))
-        for k in ("beamWidth", "batch_size", "workers", "filter_ths", "threshold", "bbox_min_score", "bbox_min_size", "max_candidates"):
+        for k in ("batch_size", "workers", "filter_ths", "threshold", "bbox_min_score", "bbox_min_size", "max_candidates"):
             kw.pop(k, None)
         pages = [reformat_input(im) for im in image]
         if n_width is not None and n_height is not None:
@@ -350,7 +355,7 @@ class Reader:
         h, f, _ = self.boxes_from_heatmap(heat, ratio, **kw)
         return [h[0]], [f[0]]
 
-    def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", detail=1, paragraph=False,
+    def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", beamWidth=5, detail=1, paragraph=False,
                   contrast_ths=0.1, adjust_contrast=0.5, reformat=True, **_ignored):
         """``Reader.recognize`` for explicit boxes of one gray page."""
         self._unsupported(decoder, None, None, None, False, "standard")
@@ -362,7 +367,8 @@ class Reader:
         if horizontal_list is None and free_list is None:
             horizontal_list, free_list = [[0, W, 0, H]], []
         return self.recognize_device(self._to_dev(img_cv_grey[None]), [horizontal_list or []], [free_list or []],
-                                     contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail)[0]
+                                     contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail, decoder=decoder,
+                                     beamWidth=beamWidth)[0]
 
     # -- stage-level entry points (tests, bench) --------------------------------------------
     def detect_dims(self, H, W, canvas_size=2560, mag_ratio=1.0):
@@ -418,8 +424,9 @@ class Reader:
 
     @staticmethod
     def _unsupported(decoder, allowlist, blocklist, rotation_info, paragraph, output_format):
-        if decoder != "greedy":
-            raise NotImplementedError("only decoder='greedy' is implemented (the reference never passes another one)")
+        if decoder not in ("greedy", "beamsearch"):
+            raise NotImplementedError("decoder='wordbeamsearch' needs easyocr's dictionary files, which are not available offline; "
+                                      "'greedy' (the reference's call) and 'beamsearch' are implemented")
         if rotation_info or output_format != "standard":
             raise NotImplementedError("rotation_info / output_format are not implemented "
                                       "(the reference calls readtext(path, paragraph=False, batch_size=1, workers=0))")

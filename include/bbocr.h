@@ -55,6 +55,8 @@ typedef struct bbocr_tensor_desc {
 } bbocr_tensor_desc;
 
 /* keyword arguments of easyocr.Reader.readtext that affect this path (same names, same defaults) */
+enum { BBOCR_DECODER_GREEDY = 0, BBOCR_DECODER_BEAMSEARCH = 1 };
+
 typedef struct bbocr_params {
     double text_threshold; /* 0.7 */
     double low_text;       /* 0.4 */
@@ -71,6 +73,10 @@ typedef struct bbocr_params {
     int min_size;          /* 20 */
     unsigned int ignore_mask[4]; /* recognizer_predict's ignore_idx as a bit mask over class indices 0..127 (allowlist / blocklist):
                                   * those classes are zeroed and the rest renormalised before the arg-max; 0 = none (english_g2 default) */
+    int decoder;           /* BBOCR_DECODER_GREEDY (0, readtext's default, the reference's call) or BBOCR_DECODER_BEAMSEARCH (1):
+                            * easyocr/utils.py::ctcBeamSearch without a language model, run on the host over the device's probabilities;
+                            * the confidence is the greedy path's custom_mean for both, as upstream computes it */
+    int beam_width;        /* 5 (readtext's beamWidth); used when decoder == BBOCR_DECODER_BEAMSEARCH */
 } bbocr_params;
 
 /* output of detection (easyocr.Reader.detect): per image horizontal_list / free_list, plus the ungrouped polygons */
@@ -148,6 +154,9 @@ int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, lon
 int bbocr_host_component_polys(const int* comps, const int* rowext, int n, int w, int h, double ratio, int* polys_out);
 /* utils.group_text_box + Reader.detect's min_size filter on n polygons of one image */
 int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr_boxlist** out);
+/* easyocr/utils.py::ctcBeamSearch (CTCLabelConverter.decode_beamsearch, no language model) on host probabilities fp32 [n,T,cs]
+ * (C <= cs classes, class 0 = blank): text_off [n+1], text_idx (<= n*T).  The host half of bbocr_params::decoder == BEAMSEARCH */
+int bbocr_host_ctc_beam(const float* probs, int n, int T, int C, int cs, int beam_width, int* text_off, int* text_idx);
 
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
@@ -159,10 +168,10 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
                     uint16_t* dev_pool_out);
 /* recogniser network only: crops bf16 [n,64,imgW] (device, already normalised) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);
-/* greedy CTC on logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n]; ignore_mask: 4 x 32-bit class mask
- * (bbocr_params::ignore_mask) or NULL */
+/* CTC decode of logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n]; ignore_mask: 4 x 32-bit class mask
+ * (bbocr_params::ignore_mask) or NULL; beam_width <= 0: greedy, > 0: ctcBeamSearch with that width (bbocr_params::decoder) */
 int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf,
-                 const unsigned int* ignore_mask);
+                 const unsigned int* ignore_mask, int beam_width);
 /* cv2.resize(INTER_LINEAR) on uint8 [N,sh,sw,C] -> [N,dh,dw,C] (device) */
 int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw);
 /* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] for the boxes whose padded width

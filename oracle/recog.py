@@ -275,6 +275,69 @@ def decode_greedy(text_index: np.ndarray, length) -> list:
     return texts
 
 
+class _BeamEntry:
+    """easyocr/utils.py::BeamEntry (no language model: prText stays 1)."""
+
+    def __init__(self):
+        self.prTotal = 0
+        self.prNonBlank = 0
+        self.prBlank = 0
+        self.prText = 1
+        self.labeling = ()
+
+
+def ctc_beam_search(mat: np.ndarray, beam_width: int = 5, ignore_idx=(0,)) -> list:
+    """easyocr/utils.py::ctcBeamSearch(mat, classes, ignore_idx, lm=None, beamWidth) -> list of class indices of the best labelling.
+
+    Restated with upstream's quirks kept: the candidate set of a step is every class with probability >= 0.5/maxC INCLUDING the blank
+    (class 0), so a labelling may carry explicit blanks; beams are ranked by prTotal * prText with Python's stable sort over dict
+    insertion order; the final string drops ``ignore_idx`` classes and any symbol equal to its predecessor IN THE LABELLING.  mat is
+    float32 and every product/sum stays float32 (python int/float operands are weak scalars in numpy arithmetic).
+    """
+    mat = np.asarray(mat, dtype=np.float32)
+    maxT, maxC = mat.shape
+    last = {(): _BeamEntry()}
+    last[()].prBlank = 1
+    last[()].prTotal = 1
+
+    def ranked(state):
+        beams = sorted(state.values(), reverse=True, key=lambda x: x.prTotal * x.prText)
+        return [b.labeling for b in beams]
+
+    for t in range(maxT):
+        curr = {}
+        for labeling in ranked(last)[:beam_width]:
+            prNonBlank = 0
+            if labeling:
+                prNonBlank = last[labeling].prNonBlank * mat[t, labeling[-1]]
+            prBlank = last[labeling].prTotal * mat[t, 0]
+            e = curr.setdefault(labeling, _BeamEntry())
+            e.labeling = labeling
+            e.prNonBlank += prNonBlank
+            e.prBlank += prBlank
+            e.prTotal += prBlank + prNonBlank
+            e.prText = last[labeling].prText
+            for c in np.where(mat[t, :] >= 0.5 / maxC)[0]:
+                c = int(c)
+                new = labeling + (c,)
+                if labeling and labeling[-1] == c:
+                    prNonBlank = mat[t, c] * last[labeling].prBlank
+                else:
+                    prNonBlank = mat[t, c] * last[labeling].prTotal
+                e2 = curr.setdefault(new, _BeamEntry())
+                e2.labeling = new
+                e2.prNonBlank += prNonBlank
+                e2.prTotal += prNonBlank
+        last = curr
+    best = ranked(last)[0]
+    return [l for i, l in enumerate(best) if l not in ignore_idx and not (i > 0 and best[i - 1] == best[i])]
+
+
+def decode_beamsearch(mat: np.ndarray, beam_width: int = 5) -> list:
+    """CTCLabelConverter.decode_beamsearch: one ctcBeamSearch per sequence of mat [b, T, C] (converter ignore_idx = [0])."""
+    return ["".join(CHARACTER[i] for i in ctc_beam_search(m, beam_width)) for m in mat]
+
+
 def softmax_f32(logits: np.ndarray) -> np.ndarray:
     """F.softmax(preds, dim=2) in float32."""
     import torch
@@ -282,8 +345,9 @@ def softmax_f32(logits: np.ndarray) -> np.ndarray:
     return torch.softmax(torch.from_numpy(np.ascontiguousarray(logits, dtype=np.float32)), dim=-1).numpy()
 
 
-def predict_from_logits(logits: np.ndarray, ignore_idx=()):
-    """recognizer_predict tail for a batch of logits [b, T, C] -> [[text, conf]]."""
+def predict_from_logits(logits: np.ndarray, ignore_idx=(), decoder="greedy", beam_width=5):
+    """recognizer_predict tail for a batch of logits [b, T, C] -> [[text, conf]] (decoder 'greedy' or 'beamsearch'; the confidence is
+    the greedy path's custom_mean for both, as upstream computes it)."""
     preds_prob = softmax_f32(logits)
     if len(ignore_idx):
         preds_prob[:, :, list(ignore_idx)] = 0.0
@@ -292,7 +356,7 @@ def predict_from_logits(logits: np.ndarray, ignore_idx=()):
     preds_prob = preds_prob.astype(np.float32)
     b, T, _ = preds_prob.shape
     preds_index = preds_prob.argmax(axis=2).reshape(-1)
-    preds_str = decode_greedy(preds_index, [T] * b)
+    preds_str = decode_greedy(preds_index, [T] * b) if decoder == "greedy" else decode_beamsearch(preds_prob, beam_width)
     values = preds_prob.max(axis=2)
     indices = preds_prob.argmax(axis=2)
     result = []

@@ -322,3 +322,26 @@ def test_paragraph_and_ignore_mask_rules():
     assert kept == sorted(kept, key=ch.index) and set(kept) == {"a", "b"} and not (w[0] & 1)
     w = ignore_mask(ch, lang, blocklist="xyz")
     assert {ch[i] for i in range(len(ch)) if (w[i >> 5] >> (i & 31)) & 1} == {"x", "y", "z"}
+
+
+@pytest.mark.parametrize("scale", [0.5, 2.0, 6.0])
+def test_host_ctc_beam_matches_oracle(lib, scale):
+    """f4: the C++ ctcBeamSearch (host half of decoder='beamsearch') against the oracle, flat to peaked distributions."""
+    from oracle import recog
+
+    rng = np.random.default_rng(int(scale * 10))
+    n, T, Cn, cs = 12, 29, 97, 112
+    lg = (rng.standard_normal((n, T, Cn)) * scale).astype(np.float32)
+    lg[:, :, 0] += rng.uniform(0, 3 * scale, size=(n, 1)).astype(np.float32)      # blank-heavy rows, as a recogniser produces
+    lg[0, 5:9, 17] += 20.0                                                         # a repeated symbol
+    pr = recog.softmax_f32(lg)
+    full = np.zeros((n, T, cs), np.float32)
+    full[:, :, :Cn] = pr
+    off = (C.c_int * (n + 1))()
+    idx = (C.c_int * (n * T))()
+    for bw in (1, 5, 9):
+        assert lib.bbocr_host_ctc_beam(full.ctypes.data_as(C.POINTER(C.c_float)), n, T, Cn, cs, bw, off, idx) == 0
+        for i in range(n):
+            assert [idx[k] for k in range(off[i], off[i + 1])] == recog.ctc_beam_search(pr[i], bw), (scale, bw, i)
+    assert lib.bbocr_host_ctc_beam(full.ctypes.data_as(C.POINTER(C.c_float)), n, T, Cn, cs, 0, off, idx) == -1     # BBOCR_ERR_ARG
+    assert lib.bbocr_host_ctc_beam(None, n, T, Cn, cs, 5, off, idx) == -1

@@ -136,7 +136,7 @@ def test_ctc_matches_oracle(reader):
     off = (C.c_int * (n + 1))()
     idx = (C.c_int * (n * T))()
     conf = (C.c_double * n)()
-    reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, None))
+    reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, None, 0))
     ref = recog.predict_from_logits(logits[:, :, :Cn])
     for i in range(n):
         text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
@@ -152,7 +152,7 @@ def test_ctc_matches_oracle(reader):
         ign = [i for i in range(Cn) if (words[i >> 5] >> (i & 31)) & 1]
         assert 0 not in ign and len(ign) > 0
         mask = (C.c_uint * 4)(*words)
-        reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, mask))
+        reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d.data_ptr()), n, T, Cn, cs, off, idx, conf, mask, 0))
         ref = recog.predict_from_logits(logits[:, :, :Cn], ignore_idx=ign)
         for i in range(n):
             text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
@@ -162,6 +162,20 @@ def test_ctc_matches_oracle(reader):
                 assert set(text) <= set(kw["allowlist"])
             else:
                 assert not (set(text) & set(kw["blocklist"]))
+    # f4: decoder='beamsearch' -- device probabilities (softmax + mask + renormalisation) into the host ctcBeamSearch; the text must equal
+    # the oracle's search on ITS float32 probabilities (ties in the ranking would expose a 1-ulp difference), the confidence is the greedy one
+    soft = (rng.standard_normal((n, T, cs)) * 1.5).astype(np.float32)
+    soft[:, :, 0] += 2.0
+    d2 = torch.from_numpy(soft).cuda()
+    for bw, mask, ign in ((5, None, ()), (3, (C.c_uint * 4)(*words), ign)):
+        reader._check(reader._lib.bbocr_op_ctc(reader._h, C.c_void_p(d2.data_ptr()), n, T, Cn, cs, off, idx, conf, mask, bw))
+        ref = recog.predict_from_logits(soft[:, :, :Cn], ignore_idx=ign, decoder="beamsearch", beam_width=bw)
+        greedy = recog.predict_from_logits(soft[:, :, :Cn], ignore_idx=ign)
+        for i in range(n):
+            text = "".join(recog.CHARACTER[idx[k]] for k in range(off[i], off[i + 1]))
+            assert text == ref[i][0], (bw, i)
+            assert conf[i] == pytest.approx(float(greedy[i][1]), rel=2e-5, abs=1e-12)
+        assert any(r[0] != g[0] for r, g in zip(ref, greedy))      # the case is not degenerate: the search changes some strings
 
 
 def test_preprocess_chain_bit_exact_vs_oracle(reader):

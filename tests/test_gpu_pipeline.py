@@ -207,7 +207,9 @@ def test_error_paths_raise(reader):
     with pytest.raises(ValueError):
         reader.readtext(np.zeros((4, 4), dtype=np.float32))
     with pytest.raises(NotImplementedError):
-        reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), decoder="beamsearch")
+        reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), decoder="wordbeamsearch")
+    with pytest.raises(NotImplementedError):
+        reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), rotation_info=[90])
     assert reader.readtext(np.full((64, 96, 3), 235, dtype=np.uint8)) == []      # blank page: no boxes, no error
 
 
@@ -299,3 +301,9 @@ def test_paragraph_and_allowlist_modes(reader):
     digits = reader.readtext(img, allowlist="0123456789")
     assert [d[0] for d in digits] == [r[0] for r in plain]                        # same boxes
     assert all(set(d[1]) <= set("0123456789") for d in digits) and any(d[1] for d in digits)
+    # decoder='beamsearch': same boxes and confidences (upstream scores the greedy path for every decoder), strings from the search
+    beam = reader.readtext(img, decoder="beamsearch", beamWidth=5)
+    assert [b[0] for b in beam] == [r[0] for r in plain] and [b[2] for b in beam] == [r[2] for r in plain]
+    assert reader.readtext(img, decoder="beamsearch", beamWidth=1) is not None
+    with pytest.raises(NotImplementedError):
+        reader.readtext(img, decoder="wordbeamsearch")

@@ -122,6 +122,39 @@ def test_ctc_matches_golden_and_edge_cases():
     assert len(recog.CHARSET) == 96 and recog.CHARACTER[0] == "[blank]" and recog.CHARSET[43] == "€"
 
 
+def test_ctc_beam_search_known_answers():
+    """f4: ctcBeamSearch restatement on hand-worked cases (C = 3: blank, 'a', 'b'; candidate threshold 0.5/3)."""
+    from oracle import recog
+
+    f = np.float32
+    # one step: candidates are every class >= 1/6; the best labelling is the most probable single symbol
+    assert recog.ctc_beam_search(np.array([[0.1, 0.7, 0.2]], f), 5) == [1]
+    assert recog.ctc_beam_search(np.array([[0.8, 0.1, 0.1]], f), 5) == []          # (0,) wins and the blank is dropped
+    # 'a' then 'a' with no blank between: labelling (1,) collects the repeat mass -> "a"
+    assert recog.ctc_beam_search(np.array([[0.02, 0.96, 0.02], [0.02, 0.96, 0.02]], f), 5) == [1]
+    # 'a', blank, 'a': labellings (1, 1) [= .96 * prBlank of (1,)] and (1, 0, 1) [= .96 * prTotal of (1, 0)] carry the SAME float32
+    # mass; the stable sort keeps (1, 1), inserted first, and upstream's final loop collapses equal neighbours of the LABELLING:
+    # "a" -- upstream's beam search cannot emit a doubled letter unless the explicit-blank labelling is strictly ahead
+    assert recog.ctc_beam_search(np.array([[0.02, 0.96, 0.02], [0.96, 0.02, 0.02], [0.02, 0.96, 0.02]], f), 5) == [1]
+    # ... which happens when the blank step also gives 'a' real mass: (1, 0) then gains .3*prNonBlank... worked by hand:
+    #   t0: (1,) .96 | t1 [.7,.3,0]: (1,) nb .288 b .672 tot .96 ; (1,0) .672 ; (1,1) .3*0 = 0
+    #   t2 [.02,.96,.02]: (1,) ext by 1 -> (1,1) = .96*.672 = .64512 ; (1,0) ext by 1 -> (1,0,1) = .96*.672 = .64512 (tie again, "a")
+    assert recog.ctc_beam_search(np.array([[0.02, 0.96, 0.02], [0.7, 0.3, 0.0], [0.02, 0.96, 0.02]], f), 5) == [1]
+    # peaked rows without doubled letters: beam search == greedy collapse
+    rng = np.random.default_rng(3)
+    lg = (rng.standard_normal((6, 40, 97)) * 12).astype(np.float32)
+    greedy = [r[0] for r in recog.predict_from_logits(lg)]
+    assert [r[0] for r in recog.predict_from_logits(lg, decoder="beamsearch")] == ["".join(c for i, c in enumerate(g) if i == 0 or g[i - 1] != c)
+                                                                                  for g in greedy]
+    # blank .6 twice, 'a' .4 twice:  t0: () .6 | (0,) .6 | (1,) .4
+    #   t1: () .36 ; (0,) = .36 [() + blank symbol] + .36 [repeat] + .36 [blank] = 1.08 ; (1,) = .24 + .16 + .24 = .64 -> (0,) wins -> ""
+    assert recog.ctc_beam_search(np.array([[0.6, 0.4, 0.0], [0.6, 0.4, 0.0]], f), 5) == []
+    # blank .45, 'a' .55 twice: (1,) = .3025 [repeat] + .2475 [blank] + .2475 [() extended] = .7975 beats (0,) = .6075 -> "a"
+    assert recog.ctc_beam_search(np.array([[0.45, 0.55, 0.0], [0.45, 0.55, 0.0]], f), 5) == [1]
+    # beam width 1 keeps only the best labelling per step
+    assert recog.ctc_beam_search(np.array([[0.45, 0.55, 0.0], [0.9, 0.1, 0.0]], f), 1) == [1]
+
+
 def test_contrast_adjust_percentiles():
     from oracle import recog
 
