@@ -566,8 +566,10 @@ static void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, dou
                        hipStream_t st) {
     if (B <= 0 || h <= 0 || w <= 0 || !(ratio > 0)) fail(BBOCR_ERR_ARG, "bad heat-map shape");
     const size_t npx = (size_t)B * h * w;
-    const int cap_comps = (int)std::min<size_t>(0x3fffffff, (size_t)B * std::max(1024, h * w / 64));
-    const int cap_rows = (int)std::min<size_t>(0x3fffffff, (size_t)B * std::max(4096, h * w / 4));
+    // theoretical maxima, so that no heat-map can overflow them: an accepted component has >= 10 pixels (getDetBoxes_core's size
+    // filter), and the (component, row) extents cannot outnumber the pixels
+    const int cap_comps = (int)std::min<size_t>(0x3fffffff, (size_t)B * ((size_t)h * w / 10 + 1));
+    const int cap_rows = (int)std::min<size_t>(0x3fffffff, npx);
     c->ccl_label.ensure(npx * 4);
     c->ccl_stat.ensure(npx * 24);
     c->ccl_slot.ensure(npx * 4);

@@ -57,6 +57,33 @@ def test_boxes_bit_exact_given_heatmap(reader):
     assert nfree > 0, "the fixture must exercise the free (slanted) box branch"
 
 
+def test_boxes_pathological_heatmaps(reader):
+    """Edge cases of S4/S5: a lattice of minimum-size components (more components than any page of text has: the buffers are sized for the
+    theoretical maximum h*w/10), one-pixel-wide strokes (one row extent per pixel), salt-and-pepper noise (thousands of rejected
+    sub-10-pixel components) and a fully saturated map (ONE component covering the page)."""
+    from oracle import boxes as obox
+
+    rng = np.random.default_rng(23)
+    h, w = 96, 128
+    heat = np.zeros((4, h, w, 2), np.float32)
+    for y in range(0, h - 3, 4):                      # 4x3-pixel blocks, one pixel apart: 12 pixels each
+        for x in range(0, w - 4, 5):
+            heat[0, y:y + 3, x:x + 4, 0] = 0.9
+    heat[1, 4:h - 4, 3:w - 3:3, 0] = 0.95             # vertical hairlines
+    heat[2, ..., 0] = (rng.random((h, w)) > 0.6) * 0.9
+    heat[2, ..., 1] = (rng.random((h, w)) > 0.9) * 0.9
+    heat[3, ..., 0] = 1.0
+    d = torch.from_numpy(heat).cuda()
+    hori, free, polys = reader.boxes_from_heatmap(d, 1.0)
+    for b in range(4):
+        oh, of, op = obox.detect_from_heatmap(heat[b, ..., 0], heat[b, ..., 1], 1.0)
+        assert [list(map(int, p)) for p in op] == polys[b], b
+        assert [list(map(int, x)) for x in oh] == hori[b], b
+        assert len(of) == len(free[b])
+    assert len(polys[0]) == (h // 4) * len(range(0, w - 4, 5)) and len(polys[0]) > h * w // 64    # beyond the old h*w/64 sizing
+    assert len(polys[1]) == len(range(3, w - 3, 3)) and len(polys[3]) == 1
+
+
 def test_heatmap_within_tolerance(reader, oracle_reader):
     from bb_ocr_amd import synth
 
@@ -194,6 +221,22 @@ def test_readtext_end_to_end(reader, oracle_reader):
     assert agree / max(total, 1) > 0.5, (agree, total)
 
 
+def test_readtext_edge_pages(reader, oracle_reader):
+    """Degenerate page shapes through the whole path: smaller than one 32-pixel canvas cell, one pixel, long strips in both directions,
+    a black page, a page whose side exceeds canvas_size (down-scaled), and a single word that fills the page edge to edge."""
+    from bb_ocr_amd import synth
+
+    word = synth.page(77, width=256, height=64, lines=1, margin=4)[0]
+    cases = [np.full((17, 33, 3), 200, np.uint8), np.full((1, 1, 3), 90, np.uint8), np.full((40, 1600, 3), 235, np.uint8),
+             np.full((900, 24, 3), 235, np.uint8), np.zeros((96, 128, 3), np.uint8), word,
+             np.ascontiguousarray(np.tile(word, (1, 12, 1))[:, :2720])]          # 2720 wide > canvas_size 2560
+    for img in cases:
+        got = reader.readtext(img)
+        want = oracle_reader.readtext(img)
+        assert [g[0] for g in got] == [[list(map(int, p)) for p in w[0]] for w in want], img.shape
+    assert reader.readtext(word) != []
+
+
 def test_readtext_batched_matches_single(reader):
     from bb_ocr_amd import synth
 
@@ -307,3 +350,19 @@ def test_paragraph_and_allowlist_modes(reader):
     assert reader.readtext(img, decoder="beamsearch", beamWidth=1) is not None
     with pytest.raises(NotImplementedError):
         reader.readtext(img, decoder="wordbeamsearch")
+
+
+def test_one_reader_called_from_worker_threads(reader):
+    """SURVEY 8(b) threading: the reference shares ONE Reader between ThreadPoolExecutor workers (batch_processor_enhanced.py:215) and calls
+    it from non-main threads (i2j_ui/app/main.py:757-771): concurrent readtext calls on one context serialise inside the library and
+    return what a sequential run returns."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from bb_ocr_amd import synth
+
+    imgs = [synth.page(500 + i, width=512 + 32 * (i % 3), height=320, lines=4, margin=20)[0] for i in range(6)]
+    seq = [reader.readtext(im) for im in imgs]
+    assert any(seq)
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        par = list(ex.map(lambda im: reader.readtext(im, paragraph=False, batch_size=1, workers=0), imgs * 2))
+    assert par == seq + seq
