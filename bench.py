@@ -98,6 +98,8 @@ def main():
         out = step()
         log(f"warm-up step done: {reader.stage_times()}")
     reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
+    if os.environ.get("BBOCR_BENCH_NOFREEZE") != "1":
+        bb_ocr_amd.freeze_gc()   # host-process hygiene of a long-running OCR worker (see freeze_gc.__doc__): full GC passes stop re-walking torch
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
