@@ -1056,34 +1056,37 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
     std::vector<unsigned int> hist(ld.size() * 256);
     HIPCHK(hipMemcpyAsync(hist.data(), c->crop_hist.p, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<uint8_t> luts(low.size() * 256);
+    // adjust_contrast_grey leaves a crop whose contrast is already >= the target untouched: its second prediction would be computed
+    // from bit-identical input, equals the first one, and get_text's `pred1[1] > pred2[1] ? pred1 : pred2` picks the same pair either
+    // way.  Only the crops that really change are run again.
+    std::vector<int> redo;
+    std::vector<uint8_t> luts;
     for (size_t k = 0; k < low.size(); ++k) {
         const size_t npx = (size_t)ld[k].rw * ld[k].rh;
         const double high = percentile_u8(&hist[k * 256], npx, 90.0), lowp = percentile_u8(&hist[k * 256], npx, 10.0);
         const double contrast = (high - lowp) / std::max(10.0, high + lowp);
-        uint8_t* lut = &luts[k * 256];
-        if (contrast < p.adjust_contrast) {
-            const double ratio = 200.0 / std::max(10.0, high - lowp);
-            for (int v = 0; v < 256; ++v) {
-                double x = ((double)v - lowp + 25) * ratio;
-                x = std::max(0.0, std::min(255.0, x));
-                lut[v] = (uint8_t)x;
-            }
-        } else {
-            for (int v = 0; v < 256; ++v) lut[v] = (uint8_t)v;
+        if (!(contrast < p.adjust_contrast)) continue;
+        const double ratio = 200.0 / std::max(10.0, high - lowp);
+        jobs[low[k]].d.lut_off = (int)luts.size();
+        for (int v = 0; v < 256; ++v) {
+            double x = ((double)v - lowp + 25) * ratio;
+            x = std::max(0.0, std::min(255.0, x));
+            luts.push_back((uint8_t)x);
         }
-        jobs[low[k]].d.lut_off = (int)(k * 256);
+        redo.push_back(low[k]);
     }
-    c->crop_luts.ensure(luts.size());
-    HIPCHK(hipMemcpyAsync(c->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<std::vector<int>> t2;
-    std::vector<double> c2;
-    recognise_pass(c, gray, H, W, jobs, low, false, t2, c2);
-    for (size_t k = 0; k < low.size(); ++k) {
-        BoxJob& j = jobs[low[k]];
-        j.d.lut_off = -1;
-        if (!(j.conf > c2[k])) { j.text = t2[k]; j.conf = c2[k]; }
+    if (!redo.empty()) {
+        c->crop_luts.ensure(luts.size());
+        HIPCHK(hipMemcpyAsync(c->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<std::vector<int>> t2;
+        std::vector<double> c2;
+        recognise_pass(c, gray, H, W, jobs, redo, false, t2, c2);
+        for (size_t k = 0; k < redo.size(); ++k) {
+            BoxJob& j = jobs[redo[k]];
+            j.d.lut_off = -1;
+            if (!(j.conf > c2[k])) { j.text = t2[k]; j.conf = c2[k]; }
+        }
     }
     c->times[6] += (float)ms_since(t0);
 }

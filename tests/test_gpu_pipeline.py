@@ -311,6 +311,25 @@ def test_full_size_batch_properties(reader):
     assert [len(p) for p in polys[:8]] == words
 
 
+def test_a4_page_batch_properties(reader):
+    """BASELINE.json configs[4] shape (dense A4 @300 dpi, 2480x3504 -> canvas 1824x2560, the resize path at full size), through the
+    same size-independent properties: the canvas geometry, copies agree, batch of 1 == batch of 4, the drawn words are detected."""
+    from bb_ocr_amd import synth
+
+    pages, words = zip(*[synth.page(4242 + i, width=2480, height=3504, lines=80, font_size=26, line_pitch=42, margin=60) for i in range(2)])
+    H32, W32, hh, hw, ratio = reader.detect_dims(3504, 2480)
+    assert (H32, W32) == (2560, 1824) and (hh, hw) == (1280, 912) and ratio == 2560 / 3504
+    rgb = torch.from_numpy(np.stack([pages[0], pages[1], pages[0], pages[1]])).cuda()
+    out = reader.readtext_device(rgb)
+    assert out[2] == out[0] and out[3] == out[1] and all(len(p) > 60 for p in out)
+    assert reader.readtext_device(rgb[1:2])[0] == out[1]
+    heat, r2 = reader.heatmap_device(rgb[:2])
+    assert tuple(heat.shape) == (2, 1280, 912, 2) and r2 == ratio
+    polys = reader.boxes_from_heatmap(heat, r2)[2]
+    # at 0.73x the narrowest word gaps close: a handful of the ~1700 words per page merge with a neighbour (the same pairs on every copy)
+    assert all(0 <= len(w) - len(p) <= 0.005 * len(w) for p, w in zip(polys, words)), ([len(p) for p in polys], [len(w) for w in words])
+
+
 def test_extractor_batching_and_tesseract_shim(reader, tmp_path):
     """f3 / a12 on the GPU: batched extraction returns exactly the per-page ``" ".join`` of ``readtext``; the pytesseract shim
     returns one line of text per rendered text line."""
