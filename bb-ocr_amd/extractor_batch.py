@@ -42,28 +42,65 @@ def ocr_input_image(image_path, image_index=None):
     return reformat_input(os.fspath(image_path))
 
 
-def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, **readtext_kw):
+def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, decode_workers=None, **readtext_kw):
     """``{index: text}`` for every index of ``ocr_image_indices`` (default: all pages), text = ``" ".join(r[1] for r in results)``
     exactly as :521; a page whose OCR fails gets ``""`` like :529-531.  Pages of equal (down-scaled) shape travel in one device
-    batch of at most ``max_batch`` pages."""
+    batch of at most ``max_batch`` pages.
+
+    Decoding (and the thumbnail + JPEG round trip) is what bounds the application once the OCR itself runs at hundreds of pages
+    per second: a 1280x960 JPEG costs ~10 ms of one core.  The files are therefore decoded by ``decode_workers`` threads (default:
+    the host's cores, at most 16; PIL releases the GIL while decoding) and a shape group is sent to the device as soon as it is
+    full, so the decode of later pages overlaps the device batch of earlier ones (ctypes releases the GIL during the C call)."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
     if ocr_image_indices is None:
         ocr_image_indices = range(len(image_paths))
     idxs = [i for i in ocr_image_indices if 0 <= i < len(image_paths)]
     texts = {i: "" for i in idxs}
-    by_shape = {}
-    for i in idxs:
+    if not idxs:
+        return texts
+    if decode_workers is None:
+        decode_workers = max(1, min(8, os.cpu_count() or 1, len(idxs)))
+
+    # three overlapped stages: decode pool -> assembler thread (groups pages by shape, stacks a full group into one host batch)
+    # -> this thread (device call + result strings).  The queue holds at most two assembled batches (2 x 300 MB at 64 pages).
+    batches = queue.Queue(maxsize=2)
+
+    def assemble():
         try:
-            rgb, gray = ocr_input_image(image_paths[i], i)
+            by_shape = {}
+            with ThreadPoolExecutor(max_workers=decode_workers) as pool:
+                futures = [(i, pool.submit(ocr_input_image, image_paths[i], i)) for i in idxs]
+                for i, fut in futures:
+                    try:
+                        rgb, gray = fut.result()
+                    except Exception:
+                        continue
+                    group = by_shape.setdefault(rgb.shape, [])
+                    group.append((i, rgb, gray))
+                    if len(group) >= max_batch:
+                        batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
+                        by_shape[rgb.shape] = []
+                for group in by_shape.values():
+                    if group:
+                        batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
+        finally:
+            batches.put(None)
+
+    worker = threading.Thread(target=assemble, daemon=True)
+    worker.start()
+    while True:
+        item = batches.get()
+        if item is None:
+            break
+        ids, rgb, gray = item
+        try:
+            res = reader.readtext_arrays(rgb, gray, **readtext_kw)
         except Exception:
             continue
-        by_shape.setdefault(rgb.shape, []).append((i, rgb, gray))
-    for _, items in by_shape.items():
-        for s in range(0, len(items), max_batch):
-            part = items[s:s + max_batch]
-            try:
-                res = reader.readtext_arrays(np.stack([p[1] for p in part]), np.stack([p[2] for p in part]), **readtext_kw)
-            except Exception:
-                continue
-            for (i, _, _), r in zip(part, res):
-                texts[i] = " ".join(item[1] for item in r)
+        for i, r in zip(ids, res):
+            texts[i] = " ".join(t[1] for t in r)
+    worker.join()
     return texts
