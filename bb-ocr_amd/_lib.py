@@ -26,7 +26,7 @@ class bbocr_params(C.Structure):
         ("text_threshold", C.c_double), ("low_text", C.c_double), ("link_threshold", C.c_double), ("mag_ratio", C.c_double),
         ("slope_ths", C.c_double), ("ycenter_ths", C.c_double), ("height_ths", C.c_double), ("width_ths", C.c_double),
         ("add_margin", C.c_double), ("contrast_ths", C.c_double), ("adjust_contrast", C.c_double),
-        ("canvas_size", C.c_int), ("min_size", C.c_int), ("ignore_mask", C.c_uint * 4), ("decoder", C.c_int), ("beam_width", C.c_int),
+        ("canvas_size", C.c_int), ("min_size", C.c_int), ("ignore_mask", C.c_uint * 4), ("decoder", C.c_int), ("beam_width", C.c_int), ("rotation_info", C.c_int * 4),
     ]
 
 
@@ -76,7 +76,7 @@ PROTOTYPES = {
                                C.POINTER(C.c_uint), C.c_int]),
     "bbocr_op_resize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
     "bbocr_op_crops": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_float,
-                                 _vp, C.POINTER(C.c_int)]),
+                                 _vp, C.POINTER(C.c_int), C.c_int]),
     "bbocr_preprocess_book_cover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bbocr_op_preprocess_stage": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_double]),
 }

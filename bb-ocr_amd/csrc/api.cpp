@@ -1007,17 +1007,71 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
     c->beam_width = p.decoder == BBOCR_DECODER_BEAMSEARCH ? p.beam_width : 0;
     jobs.clear();
     box_off.assign(B + 1, 0);
+    // rotation_info: Reader.recognize then takes its batched branch -- get_image_list over the whole page (free boxes first, result sorted
+    // by the top y of the first corner), ONE padded width for every crop of the page (max_width), the list extended by np.rot90 copies of
+    // every crop per angle (make_rotated_img_list), and per box the most confident variant kept (set_result_with_confidence)
+    int angles[4] = {0, 0, 0, 0}, nrot = 0;
+    for (int i = 0; i < 4 && p.rotation_info[i] != 0; ++i) {
+        const int a = p.rotation_info[i];
+        if (a != 90 && a != 180 && a != 270) fail(BBOCR_ERR_ARG, "rotation_info angles must be 90, 180 or 270");
+        angles[nrot++] = a;
+    }
     for (int b = 0; b < B; ++b) {
-        for (const auto& hbx : hb.hori[b]) {
-            BoxJob j;
-            if (plan_horizontal(hbx, b, H, W, j)) jobs.push_back(j);
-        }
-        for (const auto& fq : hb.freeb[b]) {
-            BoxJob j;
-            if (plan_free(fq, b, j)) jobs.push_back(j);
+        if (nrot == 0) {
+            for (const auto& hbx : hb.hori[b]) {
+                BoxJob j;
+                if (plan_horizontal(hbx, b, H, W, j)) jobs.push_back(j);
+            }
+            for (const auto& fq : hb.freeb[b]) {
+                BoxJob j;
+                if (plan_free(fq, b, j)) jobs.push_back(j);
+            }
+        } else {
+            std::vector<BoxJob> page;
+            for (const auto& fq : hb.freeb[b]) {
+                BoxJob j;
+                if (plan_free(fq, b, j)) page.push_back(j);
+            }
+            for (const auto& hbx : hb.hori[b]) {
+                BoxJob j;
+                if (plan_horizontal(hbx, b, H, W, j)) page.push_back(j);
+            }
+            std::stable_sort(page.begin(), page.end(), [](const BoxJob& x, const BoxJob& y) { return x.quad[1] < y.quad[1]; });
+            int page_w = 64;                      // max(max_width, imgH); max_width = ceil(max ratio) * 64 = the widest own bucket
+            for (const BoxJob& j : page) page_w = std::max(page_w, j.d.imgW);
+            for (BoxJob& j : page) {
+                j.d.imgW = page_w;
+                const int cw = (int)std::ceil(64 * ((double)j.d.rw / (double)j.d.rh));
+                j.d.fw = cw > page_w ? page_w : cw;
+                jobs.push_back(j);
+            }
         }
         box_off[b + 1] = (int)jobs.size();
     }
+    const size_t n_base = jobs.size();
+    for (int r = 0; r < nrot; ++r)
+        for (size_t i = 0; i < n_base; ++i) {
+            BoxJob j = jobs[i];
+            j.d.rot = angles[r] / 90;
+            if (j.d.rot & 1) std::swap(j.d.rw, j.d.rh);
+            const int cw = (int)std::ceil(64 * ((double)j.d.rw / (double)j.d.rh));       // AlignCollate on the rotated image
+            j.d.fw = cw > j.d.imgW ? j.d.imgW : cw;
+            jobs.push_back(j);
+        }
+    // the variants only live inside this function: whatever path returns, the caller sees one job per box
+    struct Collapse {
+        std::vector<BoxJob>& jobs; size_t n_base; int nrot;
+        ~Collapse() {
+            if (nrot == 0 || jobs.size() != n_base * (size_t)(nrot + 1)) return;
+            for (size_t i = 0; i < n_base; ++i) {
+                size_t best = i;
+                for (int r = 1; r <= nrot; ++r)
+                    if (jobs[(size_t)r * n_base + i].conf > jobs[best].conf) best = (size_t)r * n_base + i;     // first maximum wins
+                if (best != i) { jobs[i].text = jobs[best].text; jobs[i].conf = jobs[best].conf; }
+            }
+            jobs.resize(n_base);
+        }
+    } collapse{jobs, n_base, nrot};
     if (jobs.empty()) return;
     // scratch layout
     size_t a_total = 0, w_total = 0;
@@ -1326,7 +1380,7 @@ void bbocr_default_params(bbocr_params* p) {
     p->text_threshold = 0.7; p->low_text = 0.4; p->link_threshold = 0.4; p->canvas_size = 2560; p->mag_ratio = 1.0;
     p->slope_ths = 0.1; p->ycenter_ths = 0.5; p->height_ths = 0.5; p->width_ths = 0.5; p->add_margin = 0.1; p->min_size = 20;
     p->contrast_ths = 0.1; p->adjust_contrast = 0.5;
-    p->decoder = BBOCR_DECODER_GREEDY; p->beam_width = 5;
+    p->decoder = BBOCR_DECODER_GREEDY; p->beam_width = 5;   /* rotation_info: zeros (memset) */
 }
 
 int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
@@ -1759,21 +1813,33 @@ int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, in
 }
 
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free, int imgW,
-                   float contrast, uint16_t* dev_out, int* n_out) {
+                   float contrast, uint16_t* dev_out, int* n_out, int mode) {
     return guarded(ctx, [&] {
-        if (!dev_gray || !dev_out || !n_out || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop arguments");
+        if (!dev_gray || !dev_out || !n_out || imgW < 64 || (imgW & 63) || mode < 0 || mode > 4) fail(BBOCR_ERR_ARG, "bad crop arguments");
         std::vector<BoxJob> jobs;
+        auto take = [&](BoxJob& j) {
+            if (mode == 0) {                       // per-box branch: the boxes whose own padded width is imgW
+                if (j.d.imgW == imgW) jobs.push_back(j);
+                return;
+            }
+            j.d.imgW = imgW;                       // batched branch (rotation_info): forced width, np.rot90(crop, mode - 1)
+            j.d.rot = mode - 1;
+            if (j.d.rot & 1) std::swap(j.d.rw, j.d.rh);
+            const int cw = (int)std::ceil(64 * ((double)j.d.rw / (double)j.d.rh));
+            j.d.fw = cw > imgW ? imgW : cw;
+            jobs.push_back(j);
+        };
         for (int i = 0; i < n_hori; ++i) {
             BoxJob j;
             std::array<int, 4> b;
             memcpy(b.data(), hori + (size_t)i * 4, 16);
-            if (plan_horizontal(b, 0, H, W, j) && j.d.imgW == imgW) jobs.push_back(j);
+            if (plan_horizontal(b, 0, H, W, j)) take(j);
         }
         for (int i = 0; i < n_free; ++i) {
             BoxJob j;
             std::array<double, 8> f;
             memcpy(f.data(), free_q + (size_t)i * 8, 64);
-            if (plan_free(f, 0, j) && j.d.imgW == imgW) jobs.push_back(j);
+            if (plan_free(f, 0, j)) take(j);
         }
         *n_out = (int)jobs.size();
         if (jobs.empty()) return;

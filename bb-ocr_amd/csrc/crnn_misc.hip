@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
     if (d.warp) { src = wscratch + d.warp_off; stride = d.sw; }
     else { src = gray + (size_t)d.img * H * W + (size_t)d.sy0 * W + d.sx0; stride = W; }
     uint8_t* dst = scratch + d.a_off;
-    const int sw = d.sw, sh = d.sh, dw = d.rw, dh = d.rh;
+    // d.rw x d.rh is the stage-A image AFTER np.rot90(crop, d.rot) (rotation_info variants); cv2.resize works on the unrotated crop
+    const int sw = d.sw, sh = d.sh, dw = (d.rot & 1) ? d.rh : d.rw, dh = (d.rot & 1) ? d.rw : d.rh;
     const bool same = (dw == sw && dh == sh), area2 = (sw == 2 * dw && sh == 2 * dh);
     const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
     const int total = dw * dh;
@@ -84,7 +85,12 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const uint8_t* __restr
             v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
-        dst[i] = (uint8_t)v;
+        // np.rot90(m, k)[r][c]: k=1 m[c][W-1-r], k=2 m[H-1-r][W-1-c], k=3 m[H-1-c][r]
+        int o = i;
+        if (d.rot == 1) o = (dw - 1 - dx) * dh + dy;
+        else if (d.rot == 2) o = (dh - 1 - dy) * dw + (dw - 1 - dx);
+        else if (d.rot == 3) o = dx * dh + (dh - 1 - dy);
+        dst[o] = (uint8_t)v;
     }
 }
 
@@ -104,7 +110,6 @@ __global__ void __launch_bounds__(256) crop_hist_kernel(const uint8_t* __restric
 
 // ------------------------------------------------------------------------------------------------ PIL bicubic (8 bpc)
 #define PIL_PREC 22
-#define PIL_MAXK 132
 __device__ __forceinline__ double pil_bicubic(double x) {
     const double a = -0.5;
     if (x < 0.0) x = -x;
@@ -112,28 +117,30 @@ __device__ __forceinline__ double pil_bicubic(double x) {
     if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
     return 0.0;
 }
-// coefficients of output sample xx (Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc); returns tap count
-__device__ int pil_coeffs(int in_size, int out_size, int xx, int& xmin, int* kk) {
+// filter window of output sample xx (Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc).  The taps are evaluated on the
+// fly (pil_tap), not stored: a rotation_info variant of a long line shrinks thousands of rows to 64, i.e. hundreds of taps per sample
+struct PilWin { int x0, n; double center, ss, ww; };
+__device__ PilWin pil_window(int in_size, int out_size, int xx) {
     double scale = (double)in_size / (double)out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
     const double support = 2.0 * filterscale;
-    const double center = ((double)xx + 0.5) * scale;
-    const double ss = 1.0 / filterscale;
-    int x0 = (int)(center - support + 0.5);
+    PilWin w;
+    w.center = ((double)xx + 0.5) * scale;
+    w.ss = 1.0 / filterscale;
+    int x0 = (int)(w.center - support + 0.5);
     if (x0 < 0) x0 = 0;
-    int x1 = (int)(center + support + 0.5);
+    int x1 = (int)(w.center + support + 0.5);
     if (x1 > in_size) x1 = in_size;
-    int n = x1 - x0;
-    if (n > PIL_MAXK) n = PIL_MAXK;
-    double ww = 0.0;
-    for (int x = 0; x < n; ++x) ww += pil_bicubic(((double)(x + x0) - center + 0.5) * ss);
-    for (int x = 0; x < n; ++x) {
-        double w = pil_bicubic(((double)(x + x0) - center + 0.5) * ss);
-        if (ww != 0.0) w = w / ww;
-        kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << PIL_PREC)) : (int)(0.5 + w * (double)(1 << PIL_PREC));
-    }
-    xmin = x0;
-    return n;
+    w.x0 = x0;
+    w.n = x1 - x0;
+    w.ww = 0.0;
+    for (int x = 0; x < w.n; ++x) w.ww += pil_bicubic(((double)(x + x0) - w.center + 0.5) * w.ss);
+    return w;
+}
+__device__ __forceinline__ int pil_tap(const PilWin& w, int x) {
+    double k = pil_bicubic(((double)(x + w.x0) - w.center + 0.5) * w.ss);
+    if (w.ww != 0.0) k = k / w.ww;
+    return k < 0 ? (int)(-0.5 + k * (double)(1 << PIL_PREC)) : (int)(0.5 + k * (double)(1 << PIL_PREC));
 }
 __device__ __forceinline__ int pil_clip8(long long v) {
     const long long r = v >> PIL_PREC;
@@ -149,7 +156,6 @@ __global__ void __launch_bounds__(256) crop_pil_h_kernel(const CropDesc* __restr
     const uint8_t* lut = d.lut_off >= 0 ? luts + d.lut_off : nullptr;
     uint8_t* dst = hscratch + d.a_off;    // same offsets: fw <= rw so the region fits
     const int total = d.rh * d.fw;
-    int kk[PIL_MAXK];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int xx = i % d.fw, y = i / d.fw;
         int v;
@@ -157,13 +163,12 @@ __global__ void __launch_bounds__(256) crop_pil_h_kernel(const CropDesc* __restr
             v = src[(size_t)y * d.rw + xx];
             if (lut) v = lut[v];
         } else {
-            int xmin;
-            const int n = pil_coeffs(d.rw, d.fw, xx, xmin, kk);
+            const PilWin win = pil_window(d.rw, d.fw, xx);
             long long acc = 1LL << (PIL_PREC - 1);
-            for (int k = 0; k < n; ++k) {
-                int p = src[(size_t)y * d.rw + xmin + k];
+            for (int k = 0; k < win.n; ++k) {
+                int p = src[(size_t)y * d.rw + win.x0 + k];
                 if (lut) p = lut[p];
-                acc += (long long)p * kk[k];
+                acc += (long long)p * pil_tap(win, k);
             }
             v = pil_clip8(acc);
         }
@@ -190,14 +195,10 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int y = t >> 6, x0 = t & 63;
     if (y >= 64) return;
-    int kk[PIL_MAXK];
-    int ymin = 0, n = 0;
     const bool vert = tall && d.rh != 64;
-    if (vert) n = pil_coeffs(d.rh, 64, y, ymin, kk);
-    uint16_t* drow = dst + (size_t)y * row_stride;
-    for (int x = imgW + x0; x < imgW + gap; x += 64) drow[x] = 0;     // zero separator columns (wide layout)
-    for (int x = x0; x < imgW; x += 64) {
-        const int xs = x < d.fw ? x : d.fw - 1;
+    PilWin win;
+    if (vert) win = pil_window(d.rh, 64, y);
+    auto sample = [&](int xs) {
         int v;
         if (!tall) {
             v = src[(size_t)y * d.rw + xs];
@@ -206,11 +207,18 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
             v = src[(size_t)y * d.fw + xs];
         } else {
             long long acc = 1LL << (PIL_PREC - 1);
-            for (int k = 0; k < n; ++k) acc += (long long)src[(size_t)(ymin + k) * d.fw + xs] * kk[k];
+            for (int k = 0; k < win.n; ++k) acc += (long long)src[(size_t)(win.x0 + k) * d.fw + xs] * pil_tap(win, k);
             v = pil_clip8(acc);
         }
-        const float tv = ((float)v / 255.0f - 0.5f) / 0.5f;
-        drow[x] = f32_to_bf16_bits(tv);
+        return f32_to_bf16_bits(((float)v / 255.0f - 0.5f) / 0.5f);
+    };
+    uint16_t* drow = dst + (size_t)y * row_stride;
+    for (int x = imgW + x0; x < imgW + gap; x += 64) drow[x] = 0;     // zero separator columns (wide layout)
+    int x = x0;
+    for (; x < d.fw; x += 64) drow[x] = sample(x);
+    if (x < imgW) {                                                  // NormalizePAD: the last content column, replicated
+        const uint16_t edge = sample(d.fw - 1);
+        for (; x < imgW; x += 64) drow[x] = edge;
     }
 }
 

@@ -89,6 +89,7 @@ struct CropDesc {      // one recogniser input, filled on the host
     int a_off;         // byte offset of the stage-A (cv2-resized) crop in the crop scratch
     int lut_off;       // >= 0: contrast LUT (256 bytes) offset, -1: none
     int pad_;          // wide recogniser image: first pooled row (time step) of this crop in the sequence tensors
+    int rot;           // rotation_info variant: the stage-A image is np.rot90(resized crop, rot); rw x rh are its dimensions AFTER the rotation
     double Minv[9];    // dst -> src homography (already inverted)
 };
 // stage_mask bit0: gather (warp) + cv2 resize into scratch; bit1: (PIL bicubic) + LUT + normalise + pad into out_bucket

@@ -226,6 +226,11 @@ class Reader:
             p.ignore_mask[i] = w
         decoder = kw.get("decoder", "greedy")
         self._unsupported(decoder, None, None, None, False, "standard")
+        rotation = list(kw.get("rotation_info") or [])
+        if len(rotation) > 3 or any(a not in (90, 180, 270) for a in rotation):
+            raise ValueError("rotation_info: up to three angles out of 90, 180, 270")
+        for i, a in enumerate(rotation):
+            p.rotation_info[i] = int(a)
         if decoder == "beamsearch":          # BBOCR_DECODER_BEAMSEARCH
             p.decoder, p.beam_width = 1, int(kw.get("beamWidth", 5))
         return p
@@ -310,12 +315,12 @@ class Reader:
                   low_text=low_text, link_threshold=link_threshold, canvas_size=canvas_size, mag_ratio=mag_ratio, slope_ths=slope_ths,
                   ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail,
                   allowlist=allowlist, blocklist=blocklist, paragraph=paragraph, x_ths=x_ths, y_ths=y_ths, decoder=decoder,
-                  beamWidth=beamWidth)
+                  beamWidth=beamWidth, rotation_info=rotation_info)
         return self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]) if grey is not None else None, **kw)[0]
 
     def readtext_batched(self, image, n_width=None, n_height=None, **kw):
         """List (or 4-D array) of pages -> list of per-page results.  Equal-size pages share one device batch."""
-        self._unsupported(kw.get("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.pop("rotation_info", None),
+        self._unsupported(kw.get("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.get("rotation_info"),
                           kw.get("paragraph", False), kw.pop("output_format", "standard"))
         for k in ("batch_size", "workers", "filter_ths", "threshold", "bbox_min_score", "bbox_min_size", "max_candidates"):
             kw.pop(k, None)
@@ -356,7 +361,7 @@ class Reader:
         return [h[0]], [f[0]]
 
     def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", beamWidth=5, detail=1, paragraph=False,
-                  contrast_ths=0.1, adjust_contrast=0.5, reformat=True, **_ignored):
+                  contrast_ths=0.1, adjust_contrast=0.5, reformat=True, rotation_info=None, **_ignored):
         """``Reader.recognize`` for explicit boxes of one gray page."""
         self._unsupported(decoder, None, None, None, False, "standard")
         if paragraph:
@@ -368,7 +373,7 @@ class Reader:
             horizontal_list, free_list = [[0, W, 0, H]], []
         return self.recognize_device(self._to_dev(img_cv_grey[None]), [horizontal_list or []], [free_list or []],
                                      contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail, decoder=decoder,
-                                     beamWidth=beamWidth)[0]
+                                     beamWidth=beamWidth, rotation_info=rotation_info)[0]
 
     # -- stage-level entry points (tests, bench) --------------------------------------------
     def detect_dims(self, H, W, canvas_size=2560, mag_ratio=1.0):
@@ -427,6 +432,6 @@ class Reader:
         if decoder not in ("greedy", "beamsearch"):
             raise NotImplementedError("decoder='wordbeamsearch' needs easyocr's dictionary files, which are not available offline; "
                                       "'greedy' (the reference's call) and 'beamsearch' are implemented")
-        if rotation_info or output_format != "standard":
-            raise NotImplementedError("rotation_info / output_format are not implemented "
+        if output_format != "standard":
+            raise NotImplementedError("output_format other than 'standard' is not implemented "
                                       "(the reference calls readtext(path, paragraph=False, batch_size=1, workers=0))")

@@ -77,6 +77,10 @@ typedef struct bbocr_params {
                             * easyocr/utils.py::ctcBeamSearch without a language model, run on the host over the device's probabilities;
                             * the confidence is the greedy path's custom_mean for both, as upstream computes it */
     int beam_width;        /* 5 (readtext's beamWidth); used when decoder == BBOCR_DECODER_BEAMSEARCH */
+    int rotation_info[4];  /* readtext's rotation_info: up to three angles out of {90, 180, 270}, zero-terminated (all 0 = None, the
+                            * reference's call).  Non-empty: Reader.recognize's batched branch -- every crop of a page padded to the page's
+                            * max_width, each also recognised as np.rot90(crop, angle/90), the most confident variant reported, results
+                            * sorted by the boxes' top y */
 } bbocr_params;
 
 /* output of detection (easyocr.Reader.detect): per image horizontal_list / free_list, plus the ungrouped polygons */
@@ -174,10 +178,11 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
                  const unsigned int* ignore_mask, int beam_width);
 /* cv2.resize(INTER_LINEAR) on uint8 [N,sh,sw,C] -> [N,dh,dw,C] (device) */
 int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw);
-/* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] for the boxes whose padded width
- * is imgW (in box order); returns their count in *n_out.  contrast != 0 applies adjust_contrast_grey first. */
+/* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] (in box order); returns their count in *n_out.
+ * contrast != 0 applies adjust_contrast_grey first.  mode 0: the boxes whose own padded width is imgW (Reader.recognize's per-box
+ * branch); mode 1..4: EVERY box at the forced width imgW, rotated by np.rot90(crop, mode - 1) (the batched branch rotation_info takes) */
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free,
-                   int imgW, float contrast, uint16_t* dev_out, int* n_out);
+                   int imgW, float contrast, uint16_t* dev_out, int* n_out, int mode);
 
 /* ---- OCR pre-processing chain of the reference ----
  * pipeline_demo/ocr_testing/preprocessing/image_preprocessor.py::preprocess_for_book_cover (:147-160) on ONE decoded page:

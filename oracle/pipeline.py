@@ -47,8 +47,18 @@ class OracleReader:
     def _logits(self, x: np.ndarray) -> np.ndarray:
         return self.recognizer(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).numpy()
 
-    def recognize(self, img_cv_grey, horizontal_list, free_list, contrast_ths=0.1, adjust_contrast=0.5):
-        """Reader.recognize, per-box branch (batch_size == 1)."""
+    def recognize(self, img_cv_grey, horizontal_list, free_list, contrast_ths=0.1, adjust_contrast=0.5, rotation_info=None):
+        """Reader.recognize: per-box branch (batch_size == 1), or -- with rotation_info -- the batched branch it then takes."""
+        if rotation_info:
+            image_list, max_width = recog.get_image_list(horizontal_list, free_list, img_cv_grey, model_height=self.imgH)
+            image_len = len(image_list)
+            if image_list:
+                image_list = recog.make_rotated_img_list(rotation_info, image_list)
+                max_width = max(max_width, self.imgH)
+            result = recog.get_text(self._logits, self.imgH, int(max_width), image_list, contrast_ths, adjust_contrast)
+            if horizontal_list + free_list:
+                result = recog.set_result_with_confidence([result[image_len * i:image_len * (i + 1)] for i in range(len(rotation_info) + 1)])
+            return result
         result = []
         for bbox in horizontal_list:
             image_list, max_width = recog.get_image_list([bbox], [], img_cv_grey, model_height=self.imgH)
@@ -63,4 +73,4 @@ class OracleReader:
                     "slope_ths", "ycenter_ths", "height_ths", "width_ths", "add_margin")
         img, img_cv_grey = imgproc.reformat_input(image)
         h, f = self.detect(img, **{k: kw[k] for k in det_keys if k in kw})
-        return self.recognize(img_cv_grey, h, f, kw.get("contrast_ths", 0.1), kw.get("adjust_contrast", 0.5))
+        return self.recognize(img_cv_grey, h, f, kw.get("contrast_ths", 0.1), kw.get("adjust_contrast", 0.5), kw.get("rotation_info"))

@@ -368,6 +368,27 @@ def predict_from_logits(logits: np.ndarray, ignore_idx=(), decoder="greedy", bea
     return result
 
 
+def make_rotated_img_list(rotation_info, img_list):
+    """utils.py::make_rotated_img_list: the list extended by scipy.ndimage.rotate(crop, angle, reshape=True) per angle; for the eligible
+    angles (90, 180, 270) scipy returns exactly np.rot90(crop, angle // 90) (checked against scipy 1.x in this container)."""
+    result_img_list = img_list[:]
+    for angle in rotation_info:
+        if angle not in (90, 180, 270):
+            raise ValueError("rotation_info angles must be 90, 180 or 270")
+        for img_info in img_list:
+            result_img_list.append((img_info[0], np.ascontiguousarray(np.rot90(img_info[1], angle // 90))))
+    return result_img_list
+
+
+def set_result_with_confidence(results):
+    """utils.py::set_result_with_confidence: per box the augmentation (row) with the highest confidence; the first maximum wins."""
+    final_result = []
+    for col_ix in range(len(results[0])):
+        best_row = max([(row_ix, results[row_ix][col_ix][2]) for row_ix in range(len(results))], key=lambda x: x[1])[0]
+        final_result.append(results[best_row][col_ix])
+    return final_result
+
+
 def get_text(recognizer_fn, imgH, imgW, image_list, contrast_ths=0.1, adjust_contrast=0.5):
     """recognition.py::get_text with batch_size=1; ``recognizer_fn(x [1,1,H,W] f32) -> logits [1,T,C]``."""
     coord = [item[0] for item in image_list]

@@ -155,6 +155,26 @@ def test_ctc_beam_search_known_answers():
     assert recog.ctc_beam_search(np.array([[0.45, 0.55, 0.0], [0.9, 0.1, 0.0]], f), 1) == [1]
 
 
+def test_rotation_helpers():
+    """f4 rotation_info: make_rotated_img_list == scipy.ndimage.rotate(reshape=True) for the eligible angles (scipy is exact for multiples
+    of 90 degrees); set_result_with_confidence keeps the first maximum per box."""
+    from scipy import ndimage
+
+    from oracle import recog
+
+    rng = np.random.default_rng(9)
+    lst = [("a", rng.integers(0, 256, (64, 150), dtype=np.uint8)), ("b", rng.integers(0, 256, (96, 64), dtype=np.uint8))]
+    out = recog.make_rotated_img_list([90, 270, 180], lst)
+    assert [o[0] for o in out] == ["a", "b"] * 4 and out[0][1] is lst[0][1]
+    for k, angle in enumerate([90, 270, 180]):
+        for i in range(2):
+            assert np.array_equal(out[2 * (k + 1) + i][1], ndimage.rotate(lst[i][1], angle, reshape=True))
+    with pytest.raises(ValueError):
+        recog.make_rotated_img_list([45], lst)
+    rows = [[("p", "x", 0.2), ("q", "y", 0.9)], [("p", "X", 0.5), ("q", "Y", 0.9)], [("p", "xx", 0.5), ("q", "yy", 0.1)]]
+    assert recog.set_result_with_confidence(rows) == [("p", "X", 0.5), ("q", "y", 0.9)]
+
+
 def test_contrast_adjust_percentiles():
     from oracle import recog
 
