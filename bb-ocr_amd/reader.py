@@ -78,6 +78,25 @@ def reformat_input(image, device_gray=False):
     raise ValueError("Invalid input type. Supporting format = string(file path or url), bytes, numpy array")
 
 
+def format_output(result, output_format="standard", paragraph=False, detail=1):
+    """Tail of easyocr.Reader.readtext: ``detail == 0`` (already text only) wins, then 'dict' / 'json' re-shape each item; the confidence key
+    is spelled 'confident' upstream."""
+    if detail == 0 or output_format == "standard":
+        return result
+    if output_format == "dict":
+        if paragraph:
+            return [{"boxes": item[0], "text": item[1]} for item in result]
+        return [{"boxes": item[0], "text": item[1], "confident": item[2]} for item in result]
+    if output_format == "json":
+        import json
+
+        if paragraph:
+            return [json.dumps({"boxes": [list(map(int, lst)) for lst in item[0]], "text": item[1]}, ensure_ascii=False) for item in result]
+        return [json.dumps({"boxes": [list(map(int, lst)) for lst in item[0]], "text": item[1], "confident": item[2]}, ensure_ascii=False)
+                for item in result]
+    raise NotImplementedError(f"output_format {output_format!r}")
+
+
 def ignore_mask(character, lang_char, allowlist=None, blocklist=None):
     """easyocr.Reader.recognize's ``ignore_char`` rule as the 128-bit class mask of ``bbocr_params.ignore_mask``: with an allowlist
     every character outside it, else the blocklist, else the characters of the model that are not in the language list (none for
@@ -316,12 +335,14 @@ class Reader:
                   ycenter_ths=ycenter_ths, height_ths=height_ths, width_ths=width_ths, add_margin=add_margin, detail=detail,
                   allowlist=allowlist, blocklist=blocklist, paragraph=paragraph, x_ths=x_ths, y_ths=y_ths, decoder=decoder,
                   beamWidth=beamWidth, rotation_info=rotation_info)
-        return self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]) if grey is not None else None, **kw)[0]
+        result = self.readtext_device(self._to_dev(img[None]), self._to_dev(grey[None]) if grey is not None else None, **kw)[0]
+        return format_output(result, output_format, paragraph, detail)
 
     def readtext_batched(self, image, n_width=None, n_height=None, **kw):
         """List (or 4-D array) of pages -> list of per-page results.  Equal-size pages share one device batch."""
         self._unsupported(kw.get("decoder", "greedy"), kw.get("allowlist"), kw.get("blocklist"), kw.get("rotation_info"),
-                          kw.get("paragraph", False), kw.pop("output_format", "standard"))
+                          kw.get("paragraph", False), kw.get("output_format", "standard"))
+        output_format = kw.pop("output_format", "standard")
         for k in ("batch_size", "workers", "filter_ths", "threshold", "bbox_min_score", "bbox_min_size", "max_candidates"):
             kw.pop(k, None)
         pages = [reformat_input(im) for im in image]
@@ -338,7 +359,7 @@ class Reader:
             rgb = self._to_dev(np.stack([pages[i][0] for i in idxs]))
             gray = self._to_dev(np.stack([pages[i][1] for i in idxs]))
             for i, r in zip(idxs, self.readtext_device(rgb, gray, **kw)):
-                out[i] = r
+                out[i] = format_output(r, output_format, kw.get("paragraph", False), kw.get("detail", 1))
         return out
 
     def readtext_arrays(self, rgb, gray=None, **kw):
@@ -432,6 +453,6 @@ class Reader:
         if decoder not in ("greedy", "beamsearch"):
             raise NotImplementedError("decoder='wordbeamsearch' needs easyocr's dictionary files, which are not available offline; "
                                       "'greedy' (the reference's call) and 'beamsearch' are implemented")
-        if output_format != "standard":
-            raise NotImplementedError("output_format other than 'standard' is not implemented "
+        if output_format not in ("standard", "dict", "json"):
+            raise NotImplementedError("output_format 'free_merge' is not implemented "
                                       "(the reference calls readtext(path, paragraph=False, batch_size=1, workers=0))")

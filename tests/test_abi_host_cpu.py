@@ -345,3 +345,21 @@ def test_host_ctc_beam_matches_oracle(lib, scale):
             assert [idx[k] for k in range(off[i], off[i + 1])] == recog.ctc_beam_search(pr[i], bw), (scale, bw, i)
     assert lib.bbocr_host_ctc_beam(full.ctypes.data_as(C.POINTER(C.c_float)), n, T, Cn, cs, 0, off, idx) == -1     # BBOCR_ERR_ARG
     assert lib.bbocr_host_ctc_beam(None, n, T, Cn, cs, 5, off, idx) == -1
+
+
+def test_output_formats():
+    """f4: readtext's output_format tail ('dict' / 'json'; detail=0 wins; upstream's key is 'confident')."""
+    import json
+
+    from bb_ocr_amd.reader import format_output
+
+    res = [([[1, 2], [30, 2], [30, 12], [1, 12]], "ab", 0.5), ([[1.5, 20.0], [30.0, 21.0], [30.0, 31.0], [1.0, 30.0]], "c\u20ac", 0.25)]
+    assert format_output(res) is res and format_output(["ab"], "dict", detail=0) == ["ab"]
+    d = format_output(res, "dict")
+    assert d[0] == {"boxes": res[0][0], "text": "ab", "confident": 0.5}
+    j = [json.loads(x) for x in format_output(res, "json")]
+    assert j[1] == {"boxes": [[1, 20], [30, 21], [30, 31], [1, 30]], "text": "c\u20ac", "confident": 0.25} and "\u20ac" in format_output(res, "json")[1]
+    para = [[r[0], r[1]] for r in res]
+    assert format_output(para, "dict", paragraph=True)[0] == {"boxes": res[0][0], "text": "ab"}
+    with pytest.raises(NotImplementedError):
+        format_output(res, "free_merge")
