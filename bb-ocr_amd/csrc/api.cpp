@@ -38,9 +38,13 @@ struct StatusError {
         if (_e != hipSuccess) fail(BBOCR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
     } while (0)
 
-struct DevBuf {
+struct DevBuf {   // growable device buffer, freed with its owner (the context)
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     void ensure(size_t n) {
         if (n <= cap) return;
         if (p) (void)hipFree(p);
@@ -1424,7 +1428,7 @@ void bbocr_destroy(bbocr_ctx* c) {
     DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
                       &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
                       &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
-                      &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab};
+                      &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab, &c->ctc_probs};
     for (DevBuf* b : bufs) b->release();
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -443,3 +443,26 @@ def test_one_reader_called_from_worker_threads(reader):
     with ThreadPoolExecutor(max_workers=3) as ex:
         par = list(ex.map(lambda im: reader.readtext(im, paragraph=False, batch_size=1, workers=0), imgs * 2))
     assert par == seq + seq
+
+
+def test_context_teardown_returns_device_memory(states):
+    """Ownership: the context owns weights, work buffers, streams; close() gives all of it back.  Three create / use / close
+    cycles (every optional buffer exercised: beam-search probabilities, rotation variants, the pre-processing planes) leave the free
+    device memory where it was."""
+    import bb_ocr_amd
+    from bb_ocr_amd import synth
+
+    img = synth.page(901, width=640, height=384, lines=5, margin=24)[0]
+
+    def cycle():
+        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states)
+        assert r.readtext(img) and r.readtext(img, decoder="beamsearch") and r.readtext(img, rotation_info=[90, 180, 270])
+        r.close()
+
+    cycle()                                            # first use also initialises HIP / loads code objects
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (32 << 20)
