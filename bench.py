@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--lines", type=int, default=20)
-    ap.add_argument("--cpu-pages", type=int, default=2, help="pages for the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-pages", type=int, default=5, help="pages for the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
