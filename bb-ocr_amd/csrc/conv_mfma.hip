@@ -478,7 +478,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 // in the prologue from the uint8 RGB page -- normalizeMeanVariance + conv1_1 (3x3, 3->64) + BN + ReLU, one 27-deep (padded
 // to 64) MFMA product per 16 patch pixels -- and written straight into the two LDS patch buffers (both 32-channel chunks are
 // resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false>
+// NF (cout fragments a wave multiplies, 4 or 2): layers with <= 32 real couts in a 64-cout tile (up4b, conv_cls.0/.2/.4) skip the two
+// fragments that are pure padding (couts 32..63 of the tile, see the cout mapping of the epilogue) -- half the MFMAs, same results.
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -715,9 +717,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         constexpr int ky = tap / 3, kx = tap % 3;
         const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
         const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
-        bf16x8 af[4], bq[MF];
+        bf16x8 af[NF], bq[MF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+        for (int j = 0; j < NF; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
 #pragma unroll
         for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
         if ((c * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
@@ -728,7 +730,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+            for (int j = 0; j < NF; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
@@ -922,13 +924,17 @@ static const char* conv_stamps_dir() {
     return d;
 }
 
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false>
+template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS, FUSE1>;
-    const size_t smem = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
+    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS, FUSE1, NF>;
+    const size_t smem_max = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
+    // a single 32-channel chunk (conv_cls: Cin = 32) never touches the second patch buffer: without it a workgroup needs 33 KB and
+    // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
+    static const bool one_buf = [] { const char* e = getenv("BBOCR_CONV_1BUF"); return !(e && e[0] == '0'); }();   // A/B knob
+    const size_t smem = (one_buf && a.nchunks == 1 && !FUSE1) ? smem_max - (size_t)NPS * 64 : smem_max;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
         attr = true;
     }
@@ -970,7 +976,11 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
             if (!(npb == 6 && a.PH * a.PW == 324 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
             return launch_dma_one<WM, WN, MF, 6, 3, 324, true>(a, grid, s);
         }
-        if (three && npb == 6 && a.PH * a.PW == 324) return launch_dma_one<WM, WN, MF, 6, 3, 324>(a, grid, s);
+        if (three && npb == 6 && a.PH * a.PW == 324) {
+            static const bool half = [] { const char* e = getenv("BBOCR_CONV_NF2"); return !(e && e[0] == '0'); }();   // A/B knob
+            if (half && a.cout_store <= 32) return launch_dma_one<WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
+            return launch_dma_one<WM, WN, MF, 6, 3, 324>(a, grid, s);
+        }
         if (npb == 6) return launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
     }
     if (npb == 6) return r4 ? launch_dma_one<WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);

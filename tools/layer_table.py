@@ -7,7 +7,7 @@ path, npages = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a detector pass starts at conv1_1 (BBOCR_FUSE1=0) or at the fused conv1_2 launch (the only <..., true> 3x3 instantiation)
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('conv1_1_kernel') or ('conv3x3_dma' in r['Kernel_Name'] and 'true>' in r['Kernel_Name'])]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('conv1_1_kernel') or ('conv3x3_dma' in r['Kernel_Name'] and ', true' in r['Kernel_Name'])]
 start = idx[-1]
 k = 0; tot = 0.0; other = 0.0
 for r in rows[start:]:
