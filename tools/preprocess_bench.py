@@ -1,5 +1,5 @@
-"""Timing of the f2 pre-processing chain on one 5712x4284 page (the reference's largest photographs): device time, algorithmic
-bytes, and the CPU restatement (oracle/preprocess.py, numpy) on a down-scaled crop for scale.
+"""Timing of the f2 pre-processing chain on one 5712x4284 page (the reference's largest photographs): device time and algorithmic
+bytes.  (The oracle is test infrastructure and is not imported here; its CPU time is reported by tests/test_gpu_ops.py's chain test.)
 
   python tools/preprocess_bench.py [H W]
 """
@@ -28,10 +28,3 @@ plane = dh * dw
 alg = H * W * 4 + H * W + plane + 2 * plane + plane + 2 * plane + 12 * plane + 3 * plane
 print(f"{H}x{W} -> {dh}x{dw}: {ms:.2f} ms per page (host-synchronous call incl. 3 small D2H/H2D table round trips), "
       f"algorithmic {alg/1e6:.0f} MB -> {alg/ms/1e6:.0f} GB/s")
-if len(sys.argv) <= 3:
-    from oracle import preprocess as pp
-    small = bgr[:1071, :1428].cpu().numpy()
-    t0 = time.perf_counter()
-    pp.preprocess_for_book_cover(small)
-    cpu = time.perf_counter() - t0
-    print(f"CPU restatement (numpy, 1 thread) on a 1071x1428 crop: {cpu*1e3:.0f} ms  (x16 area -> ~{cpu*16:.1f} s for the full page)")
