@@ -1,5 +1,5 @@
 """Timing of the f2 pre-processing chain on one 5712x4284 page (the reference's largest photographs): device time and algorithmic
-bytes.  (The oracle is test infrastructure and is not imported here; its CPU time is reported by tests/test_gpu_ops.py's chain test.)
+bytes.  (The oracle is test infrastructure and is not imported here.)
 
   python tools/preprocess_bench.py [H W]
 """
