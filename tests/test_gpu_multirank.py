@@ -1,0 +1,28 @@
+"""-m gpu: the N > 1 launch of bench.py (one process per GPU, page shards, no data-path collective) rehearsed with two ranks that share the
+one card of the test box (gloo rendezvous; the driver's real runs use RCCL with one card per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_card():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+           "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo", "--batch", "8",
+           "--cpu-pages", "0"]
+    # a child process, never an exec: this pytest process has initialised the GPU
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 1
+    assert d["config"]["batch_per_gpu"] == 8 and "cpu_baseline" not in d          # the CPU leg runs at N = 1 only
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
