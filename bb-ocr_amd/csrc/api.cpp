@@ -822,8 +822,167 @@ static void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, i
 
 struct RecChunk {
     int imgW, T, first, n;   // descriptors [first, first+n) share the padded width imgW
-    size_t row0;             // first pooled row of the chunk inside its group
+    size_t row0;             // first pooled row of the chunk in the pass's sequence tensors
 };
+
+// A recognition pass = feature PARTS + one sequence stage.  A part is a set of crops standing side by side in ONE wide image
+// (CropDesc::slot = first column, 4 zero columns after every crop; ::pad_ = first pooled row), so each CRNN conv layer is a single
+// launch per part whatever the mix of widths; every part gathers its pooled time steps into the pass's shared [rows,256] tensor,
+// and the sequence stage (input projections, both BiLSTM layers, linear layers, class projection, CTC) then runs ONCE over all rows.
+// readtext_batch uses two parts: the crops of the first detector pass's pages go through the conv stack while the last pass's boxes
+// are still being extracted (CCL + host geometry), so that stretch no longer leaves the card idle.
+struct RecPart {
+    std::vector<CropDesc> descs;
+    std::vector<int> order;          // position in the pass's result vectors for each descriptor
+    std::vector<RecChunk> chunks;
+    size_t rows = 0, cols = 0;       // pooled rows / wide-image columns of this part
+    bool any_warp = false, any_tall = false;
+};
+struct RecRun {
+    std::vector<int> tiles, seqs, seq_k;   // int4 {row0, n, T, 0} per LSTM workgroup; int2 {row0, T} and result position per sequence
+    size_t rows = 0;
+    int n_results = 0;
+};
+constexpr int REC_GAP = 4;
+constexpr size_t REC_MAX_ROWS = 1500000;   // pooled time steps per sequence pass (~6.6 KB of work buffers each)
+
+// lay the crops `sel` (indices into jobs; result position = res0 + position in sel) out as one part whose rows start at row_base
+static void rec_plan_part(const std::vector<BoxJob>& jobs, const std::vector<int>& sel, int res0, size_t row_base, RecPart& part) {
+    std::map<int, std::vector<int>> buckets;          // by padded width, box order kept inside a bucket
+    for (size_t k = 0; k < sel.size(); ++k) buckets[jobs[sel[k]].d.imgW].push_back((int)k);
+    size_t rows = row_base, cols = 0;
+    for (auto& kv : buckets) {
+        const int imgW = kv.first, T = imgW / 4 - 1;
+        RecChunk ch{imgW, T, (int)part.descs.size(), (int)kv.second.size(), rows};
+        for (int i = 0; i < ch.n; ++i) {
+            const int k = kv.second[i];
+            CropDesc d = jobs[sel[k]].d;
+            if (cols > 0x7ff00000u) fail(BBOCR_ERR_OVERFLOW, "recogniser pass wider than 2^31 columns");
+            d.slot = (int)cols;
+            d.pad_ = (int)(rows + (size_t)i * T);
+            cols += (size_t)imgW + REC_GAP;
+            part.any_warp |= d.warp != 0;
+            part.any_tall |= !(d.fw == d.rw && d.rh == 64);
+            part.descs.push_back(d);
+            part.order.push_back(res0 + k);
+        }
+        rows += (size_t)ch.n * T;
+        part.chunks.push_back(ch);
+    }
+    part.rows = rows - row_base;
+    part.cols = cols;
+}
+
+// enqueue a part: descriptor upload, crops (stage A = gather / warp + cv2 resize when asked, stage B = AlignCollate into the wide image),
+// conv stack, pooled rows into seq_v.  Nothing here waits for the device (the buffers it needs are sized by the caller).
+static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, const RecPart& part, DevBuf& desc_buf, bool stage_a) {
+    if (part.descs.empty()) return;
+    desc_buf.ensure(part.descs.size() * sizeof(CropDesc));
+    const CropDesc* dd = (const CropDesc*)desc_buf.p;
+    const int n = (int)part.descs.size(), Wt = (int)part.cols;
+    HIPCHK(hipMemcpyAsync(desc_buf.p, part.descs.data(), part.descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
+    if (stage_a)
+        HIPCHK(launch_crops(gray, H, W, dd, 0, n, 0, part.any_warp, part.any_tall, (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p,
+                            (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, nullptr, 1, c->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        c->arena.begin(pass == 0);
+        uint16_t* wide = c->arena.alloc<uint16_t>((size_t)64 * Wt);
+        if (pass == 1)
+            HIPCHK(launch_crops(gray, H, W, dd, 0, n, 0, part.any_warp, part.any_tall, (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p,
+                                (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, wide, 2, c->stream, Wt, REC_GAP));
+        crnn_features_wide(c, wide, Wt, dd, 0, n, (uint16_t*)c->seq_v.p);
+        if (pass == 0) c->arena.buf.ensure(c->arena.off);
+    }
+}
+
+static void rec_add_tables(RecRun& run, const RecPart& part) {
+    for (const RecChunk& ch : part.chunks) {
+        for (int s0 = 0; s0 < ch.n; s0 += 16) {
+            run.tiles.push_back((int)(ch.row0 + (size_t)s0 * ch.T));
+            run.tiles.push_back(std::min(16, ch.n - s0));
+            run.tiles.push_back(ch.T);
+            run.tiles.push_back(0);
+        }
+        for (int i = 0; i < ch.n; ++i) {
+            run.seqs.push_back((int)(ch.row0 + (size_t)i * ch.T));
+            run.seqs.push_back(ch.T);
+            run.seq_k.push_back(part.order[ch.first + i]);
+        }
+    }
+    run.rows += part.rows;
+}
+
+// sequence stage + CTC over every row the parts of `run` produced; texts / confs are indexed by result position
+static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>& texts, std::vector<double>& confs) {
+    const size_t rows = run.rows;
+    if (rows == 0) return;
+    const size_t rows_pad = align_up(rows, 256);
+    auto t0 = clk::now();
+    {   // longest sequences first: the launch ends with the shortest tails
+        std::vector<int>& tiles = run.tiles;
+        const size_t nt = tiles.size() / 4;
+        std::vector<size_t> perm(nt);
+        for (size_t i = 0; i < nt; ++i) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) { return tiles[x * 4 + 2] > tiles[y * 4 + 2]; });
+        std::vector<int> t2(tiles.size());
+        for (size_t i = 0; i < nt; ++i) memcpy(&t2[i * 4], &tiles[perm[i] * 4], 16);
+        tiles.swap(t2);
+    }
+    const std::vector<int>&tiles = run.tiles, &seqs = run.seqs;
+    const int ntiles = (int)(tiles.size() / 4), nseq = (int)(seqs.size() / 2);
+    c->seq_logits.ensure(rows_pad * 112 * 4);
+    c->seq_tables.ensure((tiles.size() + seqs.size()) * 4);
+    int* tiles_dev = (int*)c->seq_tables.p;
+    int* seqs_dev = tiles_dev + tiles.size();
+    HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->times[4] += (float)ms_since(t0);
+    t0 = clk::now();
+    c->ctc_idx.ensure(rows * 4);
+    c->ctc_pmax.ensure(rows * 4);
+    c->ctc_out_idx.ensure(rows * 4);
+    c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
+    const bool beam = c->beam_width > 0;
+    if (beam) c->ctc_probs.ensure(rows * 112 * sizeof(float));
+    HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
+                      (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
+    std::vector<int> oidx(rows);
+    std::vector<CtcOut> oo(nseq);
+    std::vector<float> probs(beam ? rows * 112 : 0);
+    std::vector<std::vector<int>> beam_texts;
+    HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+    if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
+    for (int i = 0; i < nseq; ++i) {
+        const int k = run.seq_k[i];
+        const size_t r0 = (size_t)seqs[2 * i];
+        if (beam) texts[k] = beam_texts[i];
+        else texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
+        // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
+        confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
+    }
+    c->times[5] += (float)ms_since(t0);
+}
+
+// split `sel` into runs whose pooled rows fit one sequence pass (in width order, like the wide image)
+static std::vector<std::vector<int>> rec_split_runs(const std::vector<BoxJob>& jobs, const std::vector<int>& sel) {
+    std::vector<int> byw(sel.size());
+    for (size_t k = 0; k < sel.size(); ++k) byw[k] = (int)k;
+    std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) { return jobs[sel[x]].d.imgW < jobs[sel[y]].d.imgW; });
+    std::vector<std::vector<int>> runs(1);
+    size_t rows = 0;
+    for (int k : byw) {
+        const size_t t = (size_t)(jobs[sel[k]].d.imgW / 4 - 1);
+        if (!runs.back().empty() && rows + t > REC_MAX_ROWS) { runs.emplace_back(); rows = 0; }
+        runs.back().push_back(k);
+        rows += t;
+    }
+    return runs;
+}
 
 // run one recognition pass over `sel` (indices into jobs); descs must already carry lut_off for a contrast pass.
 static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std::vector<BoxJob>& jobs, const std::vector<int>& sel,
@@ -831,152 +990,20 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
     texts.assign(sel.size(), {});
     confs.assign(sel.size(), 0.0);
     if (sel.empty()) return;
-    // bucket by padded width, keep box order inside a bucket
-    std::map<int, std::vector<int>> buckets;
-    for (size_t k = 0; k < sel.size(); ++k) buckets[jobs[sel[k]].d.imgW].push_back((int)k);
-    std::vector<CropDesc> descs;
-    std::vector<int> order;   // position k in sel for each descriptor
-    descs.reserve(sel.size());
-    const int max_cols = c->cfg.rec_max_cols > 0 ? c->cfg.rec_max_cols : 262144;
-    const size_t max_rows = 1500000;   // pooled time steps per sequence pass (~6.6 KB of work buffers each)
-    std::vector<RecChunk> chunks;
-    for (auto& kv : buckets) {
-        const int imgW = kv.first, T = imgW / 4 - 1;
-        const int per = std::max(1, max_cols / imgW);
-        for (size_t s0 = 0; s0 < kv.second.size(); s0 += per) {
-            const int n = (int)std::min<size_t>(per, kv.second.size() - s0);
-            chunks.push_back({imgW, T, (int)descs.size(), n, 0});
-            for (int i = 0; i < n; ++i) {
-                const int k = kv.second[s0 + i];
-                CropDesc d = jobs[sel[k]].d;
-                d.slot = i;
-                descs.push_back(d);
-                order.push_back(k);
-            }
-        }
-    }
-    // groups of chunks whose pooled rows fit one sequence pass; inside a group all crops sit side by side in ONE wide image
-    // (CropDesc::slot = first column, 4 zero columns after every crop; ::pad_ = first pooled row), so each CRNN layer is a single
-    // launch for the whole group instead of one per width bucket
-    constexpr int GAP = 4;
-    std::vector<size_t> group_end;            // chunk index one past each group
-    std::vector<size_t> group_rows, group_cols;
-    for (size_t g0 = 0; g0 < chunks.size();) {
-        size_t g1 = g0, rows = 0, cols = 0;
-        while (g1 < chunks.size() && (g1 == g0 || rows + (size_t)chunks[g1].n * chunks[g1].T <= max_rows)) {
-            RecChunk& ch = chunks[g1];
-            ch.row0 = rows;
-            for (int i = 0; i < ch.n; ++i) {
-                CropDesc& d = descs[ch.first + i];
-                if (cols > 0x7ff00000u) fail(BBOCR_ERR_OVERFLOW, "recogniser pass wider than 2^31 columns");
-                d.slot = (int)cols;
-                d.pad_ = (int)(rows + (size_t)i * ch.T);
-                cols += (size_t)ch.imgW + GAP;
-            }
-            rows += (size_t)ch.n * ch.T;
-            ++g1;
-        }
-        group_end.push_back(g1);
-        group_rows.push_back(rows);
-        group_cols.push_back(cols);
-        g0 = g1;
-    }
-    c->crop_desc.ensure(descs.size() * sizeof(CropDesc));
-    auto t0 = clk::now();
-    HIPCHK(hipMemcpyAsync(c->crop_desc.p, descs.data(), descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
-    bool any_warp = false, any_tall = false;
-    for (const CropDesc& d : descs) {
-        any_warp |= d.warp != 0;
-        any_tall |= !(d.fw == d.rw && d.rh == 64);
-    }
-    if (stage_a)
-        HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, 0, (int)descs.size(), 0, any_warp, any_tall, (uint8_t*)c->crop_wscratch.p,
-                            (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, nullptr, 1, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->times[3] += (float)ms_since(t0);
-
-    size_t g0 = 0;
-    for (size_t gi = 0; gi < group_end.size(); ++gi) {
-        const size_t g1 = group_end[gi], rows = group_rows[gi];
-        const int Wt = (int)group_cols[gi];
-        const int d_first = chunks[g0].first, d_count = chunks[g1 - 1].first + chunks[g1 - 1].n - d_first;
-        const size_t rows_pad = align_up(rows, 256);
-        c->seq_v.ensure(rows_pad * 256 * 2);
-        c->seq_logits.ensure(rows_pad * 112 * 4);
-        t0 = clk::now();
-        std::vector<int> tiles, seqs;   // int4 / int2 tables
-        std::vector<int> seq_k;         // sel position of each pooled sequence
-        for (int pass = 0; pass < 2; ++pass) {
-            c->arena.begin(pass == 0);
-            uint16_t* wide = c->arena.alloc<uint16_t>((size_t)64 * Wt);
-            if (pass == 1)
-                HIPCHK(launch_crops(gray, H, W, (const CropDesc*)c->crop_desc.p, d_first, d_count, 0, any_warp, any_tall,
-                                    (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p, (uint8_t*)c->crop_hscratch.p,
-                                    (const uint8_t*)c->crop_luts.p, wide, 2, c->stream, Wt, GAP));
-            crnn_features_wide(c, wide, Wt, (const CropDesc*)c->crop_desc.p, d_first, d_count, (uint16_t*)c->seq_v.p);
-            if (pass == 0) c->arena.buf.ensure(c->arena.off);
-        }
-        for (size_t ci = g0; ci < g1; ++ci) {
-            const RecChunk& ch = chunks[ci];
-            for (int s0 = 0; s0 < ch.n; s0 += 16) {
-                tiles.push_back((int)(ch.row0 + (size_t)s0 * ch.T));
-                tiles.push_back(std::min(16, ch.n - s0));
-                tiles.push_back(ch.T);
-                tiles.push_back(0);
-            }
-            for (int i = 0; i < ch.n; ++i) {
-                seqs.push_back((int)(ch.row0 + (size_t)i * ch.T));
-                seqs.push_back(ch.T);
-                seq_k.push_back(order[ch.first + i]);
-            }
-        }
-        // longest sequences first: the launch ends with the shortest tails
-        {
-            const size_t nt = tiles.size() / 4;
-            std::vector<size_t> perm(nt);
-            for (size_t i = 0; i < nt; ++i) perm[i] = i;
-            std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) { return tiles[x * 4 + 2] > tiles[y * 4 + 2]; });
-            std::vector<int> t2(tiles.size());
-            for (size_t i = 0; i < nt; ++i) memcpy(&t2[i * 4], &tiles[perm[i] * 4], 16);
-            tiles.swap(t2);
-        }
-        const int ntiles = (int)(tiles.size() / 4), nseq = (int)(seqs.size() / 2);
-        c->seq_tables.ensure((tiles.size() + seqs.size()) * 4);
-        int* tiles_dev = (int*)c->seq_tables.p;
-        int* seqs_dev = tiles_dev + tiles.size();
-        HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
-        crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        c->times[4] += (float)ms_since(t0);
-        t0 = clk::now();
-        c->ctc_idx.ensure(rows * 4);
-        c->ctc_pmax.ensure(rows * 4);
-        c->ctc_out_idx.ensure(rows * 4);
-        c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
-        const bool beam = c->beam_width > 0;
-        if (beam) c->ctc_probs.ensure(rows * 112 * sizeof(float));
-        HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
-                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
-        std::vector<int> oidx(rows);
-        std::vector<CtcOut> oo(nseq);
-        std::vector<float> probs(beam ? rows * 112 : 0);
-        std::vector<std::vector<int>> beam_texts;
-        HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
-        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
-        for (int i = 0; i < nseq; ++i) {
-            const int k = seq_k[i];
-            const size_t r0 = (size_t)seqs[2 * i];
-            if (beam) texts[k] = beam_texts[i];
-            else texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
-            // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
-            confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
-        }
-        c->times[5] += (float)ms_since(t0);
-        g0 = g1;
+    for (const std::vector<int>& ks : rec_split_runs(jobs, sel)) {
+        // positions inside sel -> a sub-selection whose result positions are the positions in sel
+        std::vector<int> sub(ks.size());
+        for (size_t i = 0; i < ks.size(); ++i) sub[i] = sel[ks[i]];
+        RecPart part;
+        rec_plan_part(jobs, sub, 0, 0, part);
+        for (size_t i = 0; i < part.order.size(); ++i) part.order[i] = ks[part.order[i]];
+        auto t0 = clk::now();
+        c->seq_v.ensure(align_up(part.rows, 256) * 256 * 2);
+        rec_launch_part(c, gray, H, W, part, c->crop_desc, stage_a);
+        c->times[3] += (float)ms_since(t0);
+        RecRun run;
+        rec_add_tables(run, part);
+        rec_finish(c, run, texts, confs);
     }
 }
 
