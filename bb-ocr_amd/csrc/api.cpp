@@ -53,6 +53,16 @@ struct DevBuf {   // growable device buffer, freed with its owner (the context)
         HIPCHK(hipMalloc(&p, n));
         cap = n;
     }
+    void ensure_keep(size_t n, size_t used) {   // grow, keeping the first `used` bytes (waits for the device: the old buffer may be in use)
+        if (n <= cap) return;
+        void* q = nullptr;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMalloc(&q, n));
+        if (p && used) HIPCHK(hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice));
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = n;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -128,7 +138,7 @@ struct bbocr_ctx {
     DevBuf heat, gray, resized;
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
     DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
-    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs;
+    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs, crop_desc2;
     DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
 
@@ -1028,14 +1038,84 @@ static double percentile_u8(const unsigned int* hist, size_t n, double q) {
     return r;
 }
 
-static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p,
-                           std::vector<BoxJob>& jobs, std::vector<int>& box_off) {
+// State of a recognition whose FIRST feature part (the crops of pages [0, pages)) was enqueued before the boxes of the remaining pages
+// existed (readtext_batch: while the last detector pass's CCL + host geometry run).  recognize_impl picks it up and adds the rest.
+struct RecEarly {
+    bool active = false;
+    int pages = 0;
+    std::vector<BoxJob> jobs;
+    std::vector<int> box_off;        // [pages + 1]
+    size_t a_total = 0, w_total = 0; // crop scratch consumed by those jobs
+    RecPart part;
+};
+
+static void rec_check_params(bbocr_ctx* c, const bbocr_params& p) {
     if (!c->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
     if (p.ignore_mask[0] & 1u) fail(BBOCR_ERR_ARG, "the CTC blank (class 0) cannot be ignored");
     for (int i = 0; i < 4; ++i) c->ignore_mask[i] = p.ignore_mask[i];
     if (p.decoder != BBOCR_DECODER_GREEDY && p.decoder != BBOCR_DECODER_BEAMSEARCH) fail(BBOCR_ERR_ARG, "unknown decoder");
     if (p.decoder == BBOCR_DECODER_BEAMSEARCH && p.beam_width <= 0) fail(BBOCR_ERR_ARG, "beam_width must be positive");
     c->beam_width = p.decoder == BBOCR_DECODER_BEAMSEARCH ? p.beam_width : 0;
+}
+
+// Reader.recognize's per-box branch: horizontal boxes first, then free boxes, page by page
+static void rec_plan_pages(const HostBoxes& hb, int b0, int b1, int H, int W, std::vector<BoxJob>& jobs, std::vector<int>& box_off) {
+    for (int b = b0; b < b1; ++b) {
+        for (const auto& hbx : hb.hori[b]) {
+            BoxJob j;
+            if (plan_horizontal(hbx, b, H, W, j)) jobs.push_back(j);
+        }
+        for (const auto& fq : hb.freeb[b]) {
+            BoxJob j;
+            if (plan_free(fq, b, j)) jobs.push_back(j);
+        }
+        box_off[b + 1] = (int)jobs.size();
+    }
+}
+
+// crop scratch offsets of jobs [first, end), continuing at a_total / w_total
+static void rec_layout_scratch(std::vector<BoxJob>& jobs, size_t first, size_t& a_total, size_t& w_total) {
+    for (size_t i = first; i < jobs.size(); ++i) {
+        BoxJob& j = jobs[i];
+        j.d.a_off = (int)a_total;
+        a_total += align_up((size_t)j.d.rw * j.d.rh, 16);
+        if (j.d.warp) {
+            j.d.warp_off = (int)w_total;
+            w_total += align_up((size_t)j.d.sw * j.d.sh, 16);
+        }
+        if (a_total > 0x7fffffff || w_total > 0x7fffffff) fail(BBOCR_ERR_OVERFLOW, "crop scratch exceeds 2 GiB");
+    }
+}
+
+// enqueue the feature part of pages [0, pages) of a B-page batch; the buffers that must survive until the rest arrives (stage-A
+// crops for the contrast retry, pooled rows) are sized for the whole batch by extrapolation
+static void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p,
+                            RecEarly& e) {
+    rec_check_params(c, p);
+    e.box_off.assign(pages + 1, 0);
+    rec_plan_pages(hb, 0, pages, H, W, e.jobs, e.box_off);
+    if (e.jobs.empty()) return;
+    rec_layout_scratch(e.jobs, 0, e.a_total, e.w_total);
+    std::vector<int> all(e.jobs.size());
+    for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+    rec_plan_part(e.jobs, all, 0, 0, e.part);
+    const double grow = 1.25 * (double)B / (double)pages;
+    if ((double)e.part.rows * grow > (double)REC_MAX_ROWS) { e = RecEarly(); return; }   // would not fit one sequence pass: no early part
+    c->crop_scratch.ensure(std::max<size_t>((size_t)((double)e.a_total * grow), 16));
+    c->crop_hscratch.ensure(std::max<size_t>((size_t)((double)e.a_total * grow), 16));
+    c->crop_wscratch.ensure(std::max<size_t>((size_t)((double)e.w_total * grow), 16));
+    c->crop_luts.ensure(256);
+    c->seq_v.ensure(align_up((size_t)((double)e.part.rows * grow), 256) * 256 * 2);
+    auto t0 = clk::now();
+    rec_launch_part(c, gray, H, W, e.part, c->crop_desc, true);
+    c->times[3] += (float)ms_since(t0);
+    e.pages = pages;
+    e.active = true;
+}
+
+static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p,
+                           std::vector<BoxJob>& jobs, std::vector<int>& box_off, RecEarly* early = nullptr) {
+    rec_check_params(c, p);
     jobs.clear();
     box_off.assign(B + 1, 0);
     // rotation_info: Reader.recognize then takes its batched branch -- get_image_list over the whole page (free boxes first, result sorted
@@ -1047,16 +1127,18 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
         if (a != 90 && a != 180 && a != 270) fail(BBOCR_ERR_ARG, "rotation_info angles must be 90, 180 or 270");
         angles[nrot++] = a;
     }
-    for (int b = 0; b < B; ++b) {
+    const bool resume = early && early->active && nrot == 0;
+    size_t n_early = 0;
+    if (resume) {                                  // pages [0, early->pages) are planned and their feature part is on the device
+        jobs = std::move(early->jobs);
+        n_early = jobs.size();
+        for (int b = 0; b <= early->pages; ++b) box_off[b] = early->box_off[b];
+        rec_plan_pages(hb, early->pages, B, H, W, jobs, box_off);
+    }
+    for (int b = 0; b < B && !resume; ++b) {
         if (nrot == 0) {
-            for (const auto& hbx : hb.hori[b]) {
-                BoxJob j;
-                if (plan_horizontal(hbx, b, H, W, j)) jobs.push_back(j);
-            }
-            for (const auto& fq : hb.freeb[b]) {
-                BoxJob j;
-                if (plan_free(fq, b, j)) jobs.push_back(j);
-            }
+            rec_plan_pages(hb, b, b + 1, H, W, jobs, box_off);
+            continue;
         } else {
             std::vector<BoxJob> page;
             for (const auto& fq : hb.freeb[b]) {
@@ -1104,26 +1186,48 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
         }
     } collapse{jobs, n_base, nrot};
     if (jobs.empty()) return;
-    // scratch layout
-    size_t a_total = 0, w_total = 0;
-    for (BoxJob& j : jobs) {
-        j.d.a_off = (int)a_total;
-        a_total += align_up((size_t)j.d.rw * j.d.rh, 16);
-        if (j.d.warp) {
-            j.d.warp_off = (int)w_total;
-            w_total += align_up((size_t)j.d.sw * j.d.sh, 16);
-        }
-        if (a_total > 0x7fffffff || w_total > 0x7fffffff) fail(BBOCR_ERR_OVERFLOW, "crop scratch exceeds 2 GiB");
-    }
-    c->crop_scratch.ensure(std::max<size_t>(a_total, 16));
-    c->crop_hscratch.ensure(std::max<size_t>(a_total, 16));
-    c->crop_wscratch.ensure(std::max<size_t>(w_total, 16));
-    c->crop_luts.ensure(256);
-    std::vector<int> all(jobs.size());
-    for (size_t i = 0; i < jobs.size(); ++i) all[i] = (int)i;
     std::vector<std::vector<int>> texts;
     std::vector<double> confs;
-    recognise_pass(c, gray, H, W, jobs, all, true, texts, confs);
+    if (resume) {
+        size_t a_total = early->a_total, w_total = early->w_total;
+        rec_layout_scratch(jobs, n_early, a_total, w_total);
+        c->crop_scratch.ensure_keep(std::max<size_t>(a_total, 16), early->a_total);   // part 1's stage-A crops feed the contrast retry
+        c->crop_hscratch.ensure_keep(std::max<size_t>(a_total, 16), 0);
+        c->crop_wscratch.ensure_keep(std::max<size_t>(w_total, 16), 0);
+        texts.assign(jobs.size(), {});
+        confs.assign(jobs.size(), 0.0);
+        std::vector<int> rest(jobs.size() - n_early);
+        for (size_t i = 0; i < rest.size(); ++i) rest[i] = (int)(n_early + i);
+        RecPart part2;
+        rec_plan_part(jobs, rest, (int)n_early, early->part.rows, part2);
+        RecRun run;
+        rec_add_tables(run, early->part);
+        if (early->part.rows + part2.rows <= REC_MAX_ROWS) {
+            c->seq_v.ensure_keep(align_up(early->part.rows + part2.rows, 256) * 256 * 2, early->part.rows * 256 * 2);
+            auto t0 = clk::now();
+            rec_launch_part(c, gray, H, W, part2, c->crop_desc2, true);
+            c->times[3] += (float)ms_since(t0);
+            rec_add_tables(run, part2);
+            rec_finish(c, run, texts, confs);
+        } else {                                   // the rest does not fit the same sequence pass: finish part 1, then the rest on its own
+            rec_finish(c, run, texts, confs);
+            std::vector<std::vector<int>> t2;
+            std::vector<double> c2;
+            recognise_pass(c, gray, H, W, jobs, rest, true, t2, c2);
+            for (size_t i = 0; i < rest.size(); ++i) { texts[rest[i]] = t2[i]; confs[rest[i]] = c2[i]; }
+        }
+        early->active = false;
+    } else {
+        size_t a_total = 0, w_total = 0;
+        rec_layout_scratch(jobs, 0, a_total, w_total);
+        c->crop_scratch.ensure(std::max<size_t>(a_total, 16));
+        c->crop_hscratch.ensure(std::max<size_t>(a_total, 16));
+        c->crop_wscratch.ensure(std::max<size_t>(w_total, 16));
+        c->crop_luts.ensure(256);
+        std::vector<int> all(jobs.size());
+        for (size_t i = 0; i < jobs.size(); ++i) all[i] = (int)i;
+        recognise_pass(c, gray, H, W, jobs, all, true, texts, confs);
+    }
     for (size_t i = 0; i < jobs.size(); ++i) { jobs[i].text = texts[i]; jobs[i].conf = confs[i]; }
     // second round: adjust_contrast_grey for low-confidence boxes
     std::vector<int> low;
@@ -1569,6 +1673,8 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
         HIPCHK(hipEventRecord(ctx->det_t1, ctx->stream));
         HostBoxes hb;
         hb.polys.resize(B); hb.hori.resize(B); hb.freeb.resize(B);
+        RecEarly early;
+        static const bool early_on = [] { const char* e = getenv("BBOCR_REC_EARLY"); return !(e && e[0] == '0'); }();   // A/B knob
         for (size_t k = 0; k < subs.size(); ++k) {
             const int b0 = subs[k].first, nb = subs[k].second;
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->sub_events[k], 0));
@@ -1579,15 +1685,19 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
                 hb.hori[b0 + i] = std::move(part.hori[i]);
                 hb.freeb[b0 + i] = std::move(part.freeb[i]);
             }
+            // every page but the last pass's has its boxes: their crops go through the recogniser's conv stack (queued behind the
+            // detector on `stream`) while the last pass's CCL + host geometry run -- that stretch would otherwise leave the card idle
+            if (early_on && subs.size() >= 2 && k + 2 == subs.size() && pp.rotation_info[0] == 0 && ctx->crnn_loaded)
+                rec_early_begin(ctx, dev_gray, b0 + nb, B, H, W, hb, pp, early);
         }
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipEventSynchronize(ctx->det_t1));   // the detector's end, not the stream's: the early recogniser part may be running behind it
         float det_ms = 0.f;
         HIPCHK(hipEventElapsedTime(&det_ms, ctx->det_t0, ctx->det_t1));
         ctx->times[0] = det_ms;          // GPU span of the detector; box extraction (times[1], times[2]) overlaps it except for the last sub-batch
         (void)t0;
         std::vector<BoxJob> jobs;
         std::vector<int> off;
-        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off, &early);
         prof_collect(ctx);
         *out = export_result(B, jobs, off);
         ctx->times[7] = (float)ms_since(t_all);
