@@ -70,6 +70,24 @@ struct DevBuf {   // growable device buffer, freed with its owner (the context)
     }
 };
 
+struct PinBuf {   // growable pinned host buffer: the source of truly asynchronous H2D copies (a pageable source makes hipMemcpyAsync wait
+                  // for the stream first, which stalls the host exactly where it should be queueing work behind a running kernel)
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) { HIPCHK(hipDeviceSynchronize()); (void)hipHostFree(p); }     // a queued copy may still read the old buffer
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
+        cap = n;
+    }
+};
+
 struct Arena {   // bump allocator over one device buffer; a dry pass sizes it, the real pass carves it
     DevBuf buf;
     size_t off = 0;
@@ -139,6 +157,7 @@ struct bbocr_ctx {
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
     DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
     DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs, crop_desc2;
+    PinBuf desc_pin, desc_pin2;               // staging of crop_desc / crop_desc2 uploads
     DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
 
@@ -887,10 +906,14 @@ static void rec_plan_part(const std::vector<BoxJob>& jobs, const std::vector<int
 // conv stack, pooled rows into seq_v.  Nothing here waits for the device (the buffers it needs are sized by the caller).
 static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, const RecPart& part, DevBuf& desc_buf, bool stage_a) {
     if (part.descs.empty()) return;
-    desc_buf.ensure(part.descs.size() * sizeof(CropDesc));
+    const size_t bytes = part.descs.size() * sizeof(CropDesc);
+    desc_buf.ensure(bytes);
+    PinBuf& pin = (&desc_buf == &c->crop_desc2) ? c->desc_pin2 : c->desc_pin;
+    pin.ensure(bytes);
+    memcpy(pin.p, part.descs.data(), bytes);
     const CropDesc* dd = (const CropDesc*)desc_buf.p;
     const int n = (int)part.descs.size(), Wt = (int)part.cols;
-    HIPCHK(hipMemcpyAsync(desc_buf.p, part.descs.data(), part.descs.size() * sizeof(CropDesc), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(desc_buf.p, pin.p, bytes, hipMemcpyHostToDevice, c->stream));
     if (stage_a)
         HIPCHK(launch_crops(gray, H, W, dd, 0, n, 0, part.any_warp, part.any_tall, (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p,
                             (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, nullptr, 1, c->stream));
