@@ -93,6 +93,11 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     size_t xrow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) xrow[r] = ((size_t)row0 + (size_t)(g * 4 + r < n ? g * 4 + r : n - 1) * T) * 2048 + xch;
+    // x_t comes from HBM (the projection of ALL time steps was written long before), ~2 us away, and the gate math needs it ~1 us after
+    // the top of the step: threads 0..255 touch the 256 cache lines of x_{t+2} (16 sequences x 2 KB) one dword each, two steps ahead,
+    // so that the real load finds them in L2.  The value is only kept alive until the end of the step (so that hipcc accounts for it).
+    const bool pf_on = tid < 256;
+    const size_t pf_row = ((size_t)row0 + (size_t)((tid >> 4) < n ? (tid >> 4) : n - 1) * T) * 2048 + dir * 1024 + (tid & 15) * 64;
     bf16x8 sb[LSTM8_S0];
     auto stream_head = [&]() {        // fragments v = 0 .. S0-1 of the NEXT step
         gfrag_ptr wv = wv0;
@@ -138,6 +143,8 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         };
         [&]<int... V>(std::integer_sequence<int, V...>) { (visit(std::integral_constant<int, V>{}), ...); }(std::make_integer_sequence<int, 64>{});
         stream_head();               // next step's first fragments travel while the gate math runs
+        unsigned int pf = 0;         // issued AFTER the step's last weight loads: vmcnt retires in order, nothing in the MFMA phase may queue behind it
+        if (pf_on && step + 2 < T) pf = *(const unsigned int*)(xproj + pf_row + (size_t)(dir ? t - 2 : t + 2) * 2048);
         __builtin_amdgcn_sched_barrier(0);
         // gate math on PAIRS of sequences (v_pk_mul/add/fma_f32): the step is VALU-bound, and only the exp2/rcp stay scalar
         auto gate_group = [&](auto a_c) {
@@ -169,6 +176,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         };
         gate_group(std::integral_constant<int, 0>{});
         gate_group(std::integral_constant<int, 1>{});
+        asm volatile("" ::"v"(pf));
         __syncthreads();
         if (wb_seq < n) {
             const u32x4 h0 = *(const u32x4*)(hn + (wb_kg * 16 + wb_seq) * 16);
