@@ -270,22 +270,21 @@ class Reader:
             B = r.n_images
             box_off = np.ctypeslib.as_array(r.box_off, shape=(B + 1,)).tolist()
             nb = box_off[-1]
+            items = []
             if nb:
                 quads = np.ctypeslib.as_array(r.quads, shape=(nb, 8))
-                is_free = np.ctypeslib.as_array(r.is_free, shape=(nb,)).tolist()
                 text_off = np.ctypeslib.as_array(r.text_off, shape=(nb + 1,)).tolist()
                 conf = np.ctypeslib.as_array(r.conf, shape=(nb,)).tolist()
                 nt = text_off[-1]
                 # every box's text in ONE utf-32 decode, then plain str slices (a per-box join over numpy objects cost 3 ms per 64 pages)
                 chars = _CODEPOINTS[np.ctypeslib.as_array(r.text_idx, shape=(max(nt, 1),))[:nt]].tobytes().decode("utf-32-le") if nt else ""
-                qi = quads.astype(np.int64).reshape(nb, 4, 2).tolist()
-                qf = quads.reshape(nb, 4, 2).tolist()
-            for b in range(B):
-                page = []
-                for i in range(box_off[b], box_off[b + 1]):
-                    box = qf[i] if is_free[i] else qi[i]
-                    page.append((box, chars[text_off[i]:text_off[i + 1]], conf[i]))
-                out.append(page)
+                boxes = quads.astype(np.int64).reshape(nb, 4, 2).tolist()          # horizontal boxes: python ints, like upstream
+                free = np.flatnonzero(np.ctypeslib.as_array(r.is_free, shape=(nb,)))
+                if free.size:                                                        # free boxes keep their float corners
+                    for i, q in zip(free.tolist(), quads[free].reshape(-1, 4, 2).tolist()):
+                        boxes[i] = q
+                items = list(zip(boxes, [chars[a:b] for a, b in zip(text_off[:-1], text_off[1:])], conf))
+            out = [items[box_off[b]:box_off[b + 1]] for b in range(B)]
         finally:
             self._lib.bbocr_free_result(res_p)
         if detail == 0:
