@@ -873,7 +873,8 @@ struct RecRun {
     int n_results = 0;
 };
 constexpr int REC_GAP = 4;
-constexpr size_t REC_MAX_ROWS = 1500000;   // pooled time steps per sequence pass (~6.6 KB of work buffers each)
+// pooled time steps per sequence pass (~6.6 KB of work buffers each); bbocr_config::rec_max_cols (pixel columns, 4 per time step) overrides
+static size_t rec_max_rows(const bbocr_ctx* c) { return c->cfg.rec_max_cols > 0 ? (size_t)std::max(64, c->cfg.rec_max_cols / 4) : (size_t)1500000; }
 
 // lay the crops `sel` (indices into jobs; result position = res0 + position in sel) out as one part whose rows start at row_base
 static void rec_plan_part(const std::vector<BoxJob>& jobs, const std::vector<int>& sel, int res0, size_t row_base, RecPart& part) {
@@ -1002,7 +1003,7 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
 }
 
 // split `sel` into runs whose pooled rows fit one sequence pass (in width order, like the wide image)
-static std::vector<std::vector<int>> rec_split_runs(const std::vector<BoxJob>& jobs, const std::vector<int>& sel) {
+static std::vector<std::vector<int>> rec_split_runs(const bbocr_ctx* c, const std::vector<BoxJob>& jobs, const std::vector<int>& sel) {
     std::vector<int> byw(sel.size());
     for (size_t k = 0; k < sel.size(); ++k) byw[k] = (int)k;
     std::stable_sort(byw.begin(), byw.end(), [&](int x, int y) { return jobs[sel[x]].d.imgW < jobs[sel[y]].d.imgW; });
@@ -1010,7 +1011,7 @@ static std::vector<std::vector<int>> rec_split_runs(const std::vector<BoxJob>& j
     size_t rows = 0;
     for (int k : byw) {
         const size_t t = (size_t)(jobs[sel[k]].d.imgW / 4 - 1);
-        if (!runs.back().empty() && rows + t > REC_MAX_ROWS) { runs.emplace_back(); rows = 0; }
+        if (!runs.back().empty() && rows + t > rec_max_rows(c)) { runs.emplace_back(); rows = 0; }
         runs.back().push_back(k);
         rows += t;
     }
@@ -1023,7 +1024,7 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
     texts.assign(sel.size(), {});
     confs.assign(sel.size(), 0.0);
     if (sel.empty()) return;
-    for (const std::vector<int>& ks : rec_split_runs(jobs, sel)) {
+    for (const std::vector<int>& ks : rec_split_runs(c, jobs, sel)) {
         // positions inside sel -> a sub-selection whose result positions are the positions in sel
         std::vector<int> sub(ks.size());
         for (size_t i = 0; i < ks.size(); ++i) sub[i] = sel[ks[i]];
@@ -1123,7 +1124,7 @@ static void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B,
     for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
     rec_plan_part(e.jobs, all, 0, 0, e.part);
     const double grow = 1.25 * (double)B / (double)pages;
-    if ((double)e.part.rows * grow > (double)REC_MAX_ROWS) { e = RecEarly(); return; }   // would not fit one sequence pass: no early part
+    if ((double)e.part.rows * grow > (double)rec_max_rows(c)) { e = RecEarly(); return; }   // would not fit one sequence pass: no early part
     c->crop_scratch.ensure(std::max<size_t>((size_t)((double)e.a_total * grow), 16));
     c->crop_hscratch.ensure(std::max<size_t>((size_t)((double)e.a_total * grow), 16));
     c->crop_wscratch.ensure(std::max<size_t>((size_t)((double)e.w_total * grow), 16));
@@ -1225,7 +1226,7 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
         rec_plan_part(jobs, rest, (int)n_early, early->part.rows, part2);
         RecRun run;
         rec_add_tables(run, early->part);
-        if (early->part.rows + part2.rows <= REC_MAX_ROWS) {
+        if (early->part.rows + part2.rows <= rec_max_rows(c)) {
             c->seq_v.ensure_keep(align_up(early->part.rows + part2.rows, 256) * 256 * 2, early->part.rows * 256 * 2);
             auto t0 = clk::now();
             rec_launch_part(c, gray, H, W, part2, c->crop_desc2, true);

@@ -40,7 +40,7 @@ enum bbocr_status {
 typedef struct bbocr_config {
     int device;         /* HIP device ordinal */
     int det_sub_batch;  /* pages per detector pass; 0 = auto (<= 64 pages / 96 GB of activations, short last pass) */
-    int rec_max_cols;   /* pixel columns per recogniser pass; 0 = default (262144) */
+    int rec_max_cols;   /* pixel columns (4 per pooled time step) whose sequence stage runs as one pass; 0 = default (6,000,000) */
     int reserved[5];
 } bbocr_config;
 

@@ -466,3 +466,20 @@ def test_context_teardown_returns_device_memory(states):
         cycle()
     torch.cuda.synchronize()
     assert abs(torch.cuda.mem_get_info()[0] - free0) < (32 << 20)
+
+
+def test_sequence_pass_budgets_do_not_change_results(states, reader):
+    """bbocr_config::rec_max_cols bounds the pooled time steps of one sequence pass.  Small budgets split a recognition pass into several
+    runs, refuse the early feature part (first detector pass's pages) or make it finish on its own before the rest is recognised: every
+    such schedule returns exactly what the default one returns.  24 pages = detector passes [16, 8], the last 8 pages text-heavy."""
+    import bb_ocr_amd
+    from bb_ocr_amd import synth
+
+    pages = [synth.page(700 + i, width=512, height=320, lines=(2 if i < 16 else 7), margin=20)[0] for i in range(24)]
+    rgb = torch.from_numpy(np.stack(pages)).cuda()
+    want = reader.readtext_device(rgb)
+    assert sum(len(p) for p in want[16:]) > sum(len(p) for p in want[:16])
+    for cols in (1500, 12000, 40000, 90000, 105000, 118000, 130000, 160000):
+        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, rec_max_cols=cols)
+        assert r.readtext_device(rgb) == want, f"rec_max_cols={cols}"
+        r.close()
