@@ -61,7 +61,7 @@ int lstm8_xproj_channel(int dir, int gate, int unit) {
 }
 
 __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
-                                                       uint16_t* __restrict__ out, const int4* __restrict__ tiles) {
+                                                       uint16_t* __restrict__ out, const int4* __restrict__ tiles, int pf_dist) {
     static_assert(LSTM8_S0 + LSTM8_NR + LSTM8_S1 + LSTM8_NL == 64 && LSTM8_S1 <= LSTM8_S0, "fragment classes");
     constexpr int R0 = LSTM8_S0, S1 = LSTM8_S0 + LSTM8_NR, L0 = S1 + LSTM8_S1;   // first v of the register / late-streamed / LDS class
     extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     // x_t comes from HBM (the projection of ALL time steps was written long before), ~2 us away, and the gate math needs it ~1 us after
     // the top of the step: threads 0..255 touch the 256 cache lines of x_{t+2} (16 sequences x 2 KB) one dword each, two steps ahead,
     // so that the real load finds them in L2.  The value is only kept alive until the end of the step (so that hipcc accounts for it).
-    const bool pf_on = tid < 256;
+    const bool pf_on = tid < 256 && pf_dist > 0;
     const size_t pf_row = ((size_t)row0 + (size_t)((tid >> 4) < n ? (tid >> 4) : n - 1) * T) * 2048 + dir * 1024 + (tid & 15) * 64;
     bf16x8 sb[LSTM8_S0];
     auto stream_head = [&]() {        // fragments v = 0 .. S0-1 of the NEXT step
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         [&]<int... V>(std::integer_sequence<int, V...>) { (visit(std::integral_constant<int, V>{}), ...); }(std::make_integer_sequence<int, 64>{});
         stream_head();               // next step's first fragments travel while the gate math runs
         unsigned int pf = 0;         // issued AFTER the step's last weight loads: vmcnt retires in order, nothing in the MFMA phase may queue behind it
-        if (pf_on && step + 2 < T) pf = *(const unsigned int*)(xproj + pf_row + (size_t)(dir ? t - 2 : t + 2) * 2048);
+        if (pf_on && step + pf_dist < T) pf = *(const unsigned int*)(xproj + pf_row + (size_t)(dir ? t - pf_dist : t + pf_dist) * 2048);
         __builtin_amdgcn_sched_barrier(0);
         // gate math on PAIRS of sequences (v_pk_mul/add/fma_f32): the step is VALU-bound, and only the exp2/rcp stay scalar
         auto gate_group = [&](auto a_c) {
@@ -195,6 +195,7 @@ hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* 
         if (e != hipSuccess) return e;
         attr8 = true;
     }
-    hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev);
+    static const int pf_dist = [] { const char* e = getenv("BBOCR_LSTM_PF"); return e ? atoi(e) : 2; }();   // x prefetch distance in steps (0 = off)
+    hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev, pf_dist);
     return hipGetLastError();
 }
