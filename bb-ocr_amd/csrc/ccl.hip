@@ -29,15 +29,38 @@ __device__ __forceinline__ void ccl_union(int* label, int a, int b) {
     }
 }
 
-__global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, size_t total, float low_text, float link_thr,
+// Initial labels: every foreground pixel starts as the FIRST pixel of its horizontal run inside its 64-pixel wave segment (ballot +
+// count-leading-zeros, no memory traffic), not as itself: a run is then already one set, and the merge kernel only has to unite runs
+// where they first touch -- an order of magnitude fewer union-find walks than two per foreground pixel.  (i & 63) == lane because the
+// grid stride is a multiple of 256.
+__global__ void __launch_bounds__(256) ccl_init_kernel(const float* __restrict__ heat, size_t total, int w, float low_text, float link_thr,
                                                        int* __restrict__ label, int* __restrict__ stat, int* __restrict__ slot) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const float2 v = *(const float2*)(heat + i * 2);
-        const bool fg = (v.x > low_text) || (v.y > link_thr);
-        label[i] = fg ? (int)i : -1;
-        slot[i] = -1;
-        int* st = stat + i * 6;
-        st[0] = 0x7fffffff; st[1] = -1; st[2] = 0x7fffffff; st[3] = -1; st[4] = 0; st[5] = 0;
+    const int lane = threadIdx.x & 63;
+    const size_t nround = (total + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    for (size_t it = 0; it < nround; ++it) {
+        const size_t i = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        bool fg = false;
+        int x = 0;
+        if (i < total) {
+            const float2 v = *(const float2*)(heat + i * 2);
+            fg = (v.x > low_text) || (v.y > link_thr);
+            x = (int)(i % w);
+        }
+        const unsigned long long fgm = __ballot(fg);
+        // a run starts at lane 0, at a row start, or after a background lane
+        const bool start = fg && (lane == 0 || x == 0 || !((fgm >> (lane - 1)) & 1ULL));
+        const unsigned long long sm = __ballot(start);
+        if (i < total) {
+            int lab = -1;
+            if (fg) {
+                const unsigned long long below = sm & ((lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL));
+                lab = (int)i - (lane - (63 - __clzll((long long)below)));
+            }
+            label[i] = lab;
+            slot[i] = -1;
+            int* st = stat + i * 6;
+            st[0] = 0x7fffffff; st[1] = -1; st[2] = 0x7fffffff; st[3] = -1; st[4] = 0; st[5] = 0;
+        }
     }
 }
 
@@ -46,8 +69,12 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(size_t total, int h, int
         if (label[i] < 0) continue;
         const int x = (int)(i % w);
         const int y = (int)((i / w) % h);
-        if (x > 0 && label[i - 1] >= 0) ccl_union(label, (int)i, (int)i - 1);
-        if (y > 0 && label[i - w] >= 0) ccl_union(label, (int)i, (int)i - w);
+        const bool left = x > 0 && label[i - 1] >= 0;
+        // horizontal: only where a run continues across a wave-segment boundary (inside a segment the run is one set already)
+        if (left && (i & 63) == 0) ccl_union(label, (int)i, (int)i - 1);
+        // vertical: only at the first contact of the two runs -- if my left neighbour and ITS upper neighbour are both foreground, that
+        // pixel (or one further left) has united the same two runs
+        if (y > 0 && label[i - w] >= 0 && !(left && label[i - w - 1] >= 0)) ccl_union(label, (int)i, (int)i - w);
     }
 }
 
@@ -152,7 +179,7 @@ hipError_t launch_ccl(const float* heat, int N, int h, int w, float low_text, fl
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, heat, total, low_text, link_thr, label, stat, slot);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, heat, total, w, low_text, link_thr, label, stat, slot);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid), dim3(256), 0, s, total, h, w, label);
     hipLaunchKernelGGL(ccl_stats_kernel, dim3(grid), dim3(256), 0, s, heat, total, h, w, label, stat);
     hipLaunchKernelGGL(ccl_accept_kernel, dim3(grid), dim3(256), 0, s, total, h * w, text_thr, label, stat, slot, comps, rowext, counters,
