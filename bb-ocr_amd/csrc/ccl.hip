@@ -152,22 +152,36 @@ __global__ void __launch_bounds__(256) ccl_accept_kernel(size_t total, int hw, d
     }
 }
 
+// per-row x-extremes of the TEXT pixels of every accepted component.  Like ccl_stats_kernel, lanes that continue the previous lane's
+// component in the same row form a run and only the run's first lane touches the row's two counters (min = run start, max = run end).
 __global__ void __launch_bounds__(256) ccl_rowext_kernel(const float* __restrict__ heat, size_t total, int h, int w, float low_text,
                                                          const int* __restrict__ label, const int* __restrict__ slot,
                                                          const CclOut* __restrict__ comps, int* rowext, int cap_comps, int cap_rows) {
-    const int hw = h * w;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = label[i];
-        if (r < 0) continue;
-        if (!(heat[i * 2] > low_text)) continue;   // link-only pixels are removed from the segmentation map
-        const int s = slot[r];
-        if (s < 0) continue;
-        const CclOut c = comps[s];
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        int* re = rowext + ((size_t)c.row_off + (y - c.top)) * 2;
-        atomicMin(re, x);
-        atomicMax(re + 1, x);
+    const int lane = threadIdx.x & 63;
+    const size_t nround = (total + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    for (size_t it = 0; it < nround; ++it) {
+        const size_t i = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        int r = -1, x = 0;
+        if (i < total) {
+            r = label[i];
+            if (r >= 0 && !(heat[i * 2] > low_text)) r = -1;   // link-only pixels are removed from the segmentation map
+            x = (int)(i % w);
+        }
+        const int rp = __shfl_up(r, 1);
+        const bool head = r >= 0 && (lane == 0 || rp != r || x == 0);
+        const unsigned long long hm = __ballot(head || r < 0);
+        if (head) {
+            const int s = slot[r];
+            if (s >= 0) {
+                const unsigned long long above = (lane == 63) ? 0ULL : (hm >> (lane + 1));
+                const int len_after = above ? (__ffsll((long long)above) - 1) : (63 - lane);   // lanes of this run after me
+                const CclOut c = comps[s];
+                const int y = (int)((i / w) % h);
+                int* re = rowext + ((size_t)c.row_off + (y - c.top)) * 2;
+                atomicMin(re, x);
+                atomicMax(re + 1, x + len_after);
+            }
+        }
     }
 }
 
