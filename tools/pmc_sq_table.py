@@ -12,7 +12,7 @@ for r in csv.DictReader(open(f)):
     d = disp.setdefault(k, {"kernel": r["Kernel_Name"], "grid": r["Grid_Size"]})
     d[r["Counter_Name"]] = float(r["Counter_Value"])
 conv = [(k, d) for k, d in sorted(disp.items()) if any(s in d["kernel"] for s in ("conv3x3_dma", "conv1x1_dma", "conv_mfma"))]
-start = max(i for i, (k, d) in enumerate(conv) if "conv3x3_dma" in d["kernel"] and "true>" in d["kernel"])
+start = max(i for i, (k, d) in enumerate(conv) if "conv3x3_dma" in d["kernel"] and ", true" in d["kernel"])
 w = csv.writer(sys.stdout)
 w.writerow(["layer", "dispatch", "kernel", "grid"] + cols + ["wait_any_pct", "wait_inst_pct", "active_pct"])
 for i, (k, d) in enumerate(conv[start:start + len(names)]):

@@ -15,7 +15,7 @@ def per_layer(d, counter):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     conv = [r for r in rows if "conv3x3_dma" in r["Kernel_Name"] or "conv1x1_dma" in r["Kernel_Name"] or "conv_mfma" in r["Kernel_Name"]]
-    start = max(i for i, r in enumerate(conv) if "conv3x3_dma" in r["Kernel_Name"] and "true>" in r["Kernel_Name"])   # fused conv1_2 = first launch of a pass
+    start = max(i for i, r in enumerate(conv) if "conv3x3_dma" in r["Kernel_Name"] and ", true" in r["Kernel_Name"])   # fused conv1_2 = first launch of a pass
     return [(r["Kernel_Name"][:r["Kernel_Name"].find("(")], float(r["Counter_Value"])) for r in conv[start:]]
 
 fd, wd, npages, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
