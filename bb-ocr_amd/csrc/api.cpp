@@ -158,6 +158,7 @@ struct bbocr_ctx {
     DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
     DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs, crop_desc2;
     PinBuf desc_pin, desc_pin2;               // staging of crop_desc / crop_desc2 uploads
+    PinBuf ctc_pin;                           // CTC results land here (pinned: the 1.7 MB D2H copy of a 64-page pass runs at link speed)
     DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
 
@@ -982,12 +983,14 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
     if (beam) c->ctc_probs.ensure(rows * 112 * sizeof(float));
     HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
                       (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
-    std::vector<int> oidx(rows);
-    std::vector<CtcOut> oo(nseq);
+    const size_t oo_off = align_up(rows * 4, 16);
+    c->ctc_pin.ensure(oo_off + (size_t)nseq * sizeof(CtcOut));
+    const int* oidx = (const int*)c->ctc_pin.p;
+    const CtcOut* oo = (const CtcOut*)((const char*)c->ctc_pin.p + oo_off);
     std::vector<float> probs(beam ? rows * 112 : 0);
     std::vector<std::vector<int>> beam_texts;
-    HIPCHK(hipMemcpyAsync(oidx.data(), c->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(oo.data(), c->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ctc_pin.p, c->ctc_out_idx.p, rows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync((char*)c->ctc_pin.p + oo_off, c->ctc_out.p, (size_t)nseq * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
     if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
@@ -995,7 +998,7 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
         const int k = run.seq_k[i];
         const size_t r0 = (size_t)seqs[2 * i];
         if (beam) texts[k] = beam_texts[i];
-        else texts[k].assign(oidx.begin() + r0, oidx.begin() + r0 + oo[i].len);
+        else texts[k].assign(oidx + r0, oidx + r0 + oo[i].len);
         // custom_mean: prod ** (2 / sqrt(len)); an all-blank sequence scores np.array([0])
         confs[k] = oo[i].cnt > 0 ? std::pow((double)oo[i].prod, 2.0 / std::sqrt((double)oo[i].cnt)) : 0.0;
     }
