@@ -1293,8 +1293,7 @@ static void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int 
     }
     if (!redo.empty()) {
         c->crop_luts.ensure(luts.size());
-        HIPCHK(hipMemcpyAsync(c->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyAsync(c->crop_luts.p, luts.data(), luts.size(), hipMemcpyHostToDevice, c->stream));   // `luts` outlives the pass below, which ends synchronised
         std::vector<std::vector<int>> t2;
         std::vector<double> c2;
         recognise_pass(c, gray, H, W, jobs, redo, false, t2, c2);
