@@ -483,3 +483,22 @@ def test_sequence_pass_budgets_do_not_change_results(states, reader):
         r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, rec_max_cols=cols)
         assert r.readtext_device(rgb) == want, f"rec_max_cols={cols}"
         r.close()
+
+
+def test_random_batches_match_single_pages(reader):
+    """Seeded sweep over batch sizes (1 .. 40 pages: detector pass schedules [B], [B-8, 8], with and without the early recogniser part), page
+    sizes (on and off the 32-pixel grid, i.e. with and without the canvas resize) and text densities: the batch result equals the
+    page-by-page results, page for page."""
+    from bb_ocr_amd import synth
+
+    rng = np.random.default_rng(2024)
+    for case in range(6):
+        B = int(rng.choice([1, 3, 9, 24, 31, 40]))
+        W = int(rng.choice([320, 416, 500, 640]))
+        H = int(rng.choice([192, 250, 288]))
+        pages = [synth.page(9000 + 50 * case + i, width=W, height=H, lines=int(rng.integers(0, 6)), margin=16)[0] for i in range(B)]
+        rgb = torch.from_numpy(np.stack(pages)).cuda()
+        got = reader.readtext_device(rgb)
+        idx = sorted(set(rng.integers(0, B, size=min(B, 5)).tolist()) | {0, B - 1})
+        for i in idx:
+            assert reader.readtext_device(rgb[i:i + 1])[0] == got[i], (case, B, W, H, i)
