@@ -1,0 +1,252 @@
+// C ABI of libbbocr (include/bbocr.h): context life cycle, weights, the detect / boxes / recognise / readtext pipelines, pre-processing chain, profiling.
+#include "ctx.h"
+
+extern "C" {
+
+void bbocr_default_params(bbocr_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->text_threshold = 0.7; p->low_text = 0.4; p->link_threshold = 0.4; p->canvas_size = 2560; p->mag_ratio = 1.0;
+    p->slope_ths = 0.1; p->ycenter_ths = 0.5; p->height_ths = 0.5; p->width_ths = 0.5; p->add_margin = 0.1; p->min_size = 20;
+    p->contrast_ths = 0.1; p->adjust_contrast = 0.5;
+    p->decoder = BBOCR_DECODER_GREEDY; p->beam_width = 5;   /* rotation_info: zeros (memset) */
+}
+
+int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
+    if (!out) return BBOCR_ERR_ARG;
+    *out = nullptr;
+    bbocr_ctx* c = nullptr;
+    try {
+        c = new bbocr_ctx();
+        if (cfg) c->cfg = *cfg;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->cfg.device < 0 || c->cfg.device >= ndev) {
+            delete c;
+            return BBOCR_ERR_HIP;
+        }
+        if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+            delete c;
+            return BBOCR_ERR_HIP;
+        }
+    } catch (...) {
+        delete c;
+        return BBOCR_ERR_INTERNAL;
+    }
+    c->cur = c->stream;
+    *out = c;
+    return BBOCR_OK;
+}
+
+void bbocr_destroy(bbocr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
+    if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
+    if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }
+    for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
+    free_weights(c);
+    DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
+                      &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
+                      &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
+                      &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab, &c->ctc_probs};
+    for (DevBuf* b : bufs) b->release();
+    if (c->zero_page) (void)hipFree(c->zero_page);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    delete c;
+}
+
+const char* bbocr_last_error(bbocr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n) {
+    return guarded(ctx, [&] {
+        if (!descs || n <= 0 || (which != 0 && which != 1)) fail(BBOCR_ERR_ARG, "bad weight descriptor table");
+        TensorMap tm(descs, n);
+        if (which == 0) load_craft(ctx, tm);
+        else load_crnn(ctx, tm);
+    });
+}
+
+int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio) {
+    if (H <= 0 || W <= 0 || canvas_size <= 0) return BBOCR_ERR_ARG;
+    const DetDims d = det_dims(H, W, canvas_size, (double)mag_ratio);
+    if (H32) *H32 = d.H32;
+    if (W32) *W32 = d.W32;
+    if (rh) *rh = d.h;
+    if (rw) *rw = d.w;
+    if (ratio) *ratio = d.ratio;
+    return BBOCR_OK;
+}
+
+int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, const bbocr_params* p, float* dev_heat_out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_rgb || !dev_heat_out) fail(BBOCR_ERR_ARG, "null device pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        detect_impl(ctx, dev_rgb, B, H, W, pp, dev_heat_out);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        prof_collect(ctx);
+        ctx->times[0] = ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, double ratio, const bbocr_params* p, bbocr_boxlist** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_heat || !out) fail(BBOCR_ERR_ARG, "null pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        HostBoxes hb;
+        boxes_impl(ctx, dev_heat, B, h, w, ratio, pp, hb, ctx->stream);
+        *out = export_boxes(hb);
+        ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W, const bbocr_boxlist* boxes, const bbocr_params* p,
+                    bbocr_result** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_gray || !boxes || !out || boxes->n_images != B) fail(BBOCR_ERR_ARG, "bad recognise arguments");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t0 = clk::now();
+        HostBoxes hb;
+        import_boxes(boxes, hb);
+        std::vector<BoxJob> jobs;
+        std::vector<int> off;
+        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off);
+        prof_collect(ctx);
+        *out = export_result(B, jobs, off);
+        ctx->times[7] = (float)ms_since(t0);
+    });
+}
+
+int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* dev_gray, int B, int H, int W, const bbocr_params* p,
+                         bbocr_result** out) {
+    return guarded(ctx, [&] {
+        bbocr_params pp;
+        bbocr_default_params(&pp);
+        if (p) pp = *p;
+        if (!dev_rgb || !out) fail(BBOCR_ERR_ARG, "null pointer");
+        memset(ctx->times, 0, sizeof(ctx->times));
+        auto t_all = clk::now();
+        const DetDims d = det_dims(H, W, pp.canvas_size, pp.mag_ratio);
+        ctx->heat.ensure((size_t)B * d.h * d.w * 2 * sizeof(float));
+        if (!dev_gray) {
+            ctx->gray.ensure((size_t)B * H * W);
+            HIPCHK(launch_gray(dev_rgb, (uint8_t*)ctx->gray.p, (size_t)B * H * W, ctx->stream));
+            dev_gray = (const uint8_t*)ctx->gray.p;
+        }
+        auto t0 = clk::now();
+        // The whole detector is enqueued first (one event per sub-batch, no host wait); box extraction of sub-batch k then
+        // runs on the second stream + host threads while sub-batch k+1 is still in the detector.
+        std::vector<std::pair<int, int>> subs;
+        if (!ctx->det_t0) { HIPCHK(hipEventCreate(&ctx->det_t0)); HIPCHK(hipEventCreate(&ctx->det_t1)); }
+        HIPCHK(hipEventRecord(ctx->det_t0, ctx->stream));
+        detect_impl(ctx, dev_rgb, B, H, W, pp, (float*)ctx->heat.p, [&](int b0, int nb) {
+            if (subs.size() >= ctx->sub_events.size()) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->sub_events.push_back(e);
+            }
+            HIPCHK(hipEventRecord(ctx->sub_events[subs.size()], ctx->stream));
+            subs.push_back({b0, nb});
+        });
+        HIPCHK(hipEventRecord(ctx->det_t1, ctx->stream));
+        HostBoxes hb;
+        hb.polys.resize(B); hb.hori.resize(B); hb.freeb.resize(B);
+        RecEarly early;
+        static const bool early_on = [] { const char* e = getenv("BBOCR_REC_EARLY"); return !(e && e[0] == '0'); }();   // A/B knob
+        for (size_t k = 0; k < subs.size(); ++k) {
+            const int b0 = subs[k].first, nb = subs[k].second;
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->sub_events[k], 0));
+            HostBoxes part;
+            boxes_impl(ctx, (const float*)ctx->heat.p + (size_t)b0 * d.h * d.w * 2, nb, d.h, d.w, d.ratio, pp, part, ctx->stream2);
+            for (int i = 0; i < nb; ++i) {
+                hb.polys[b0 + i] = std::move(part.polys[i]);
+                hb.hori[b0 + i] = std::move(part.hori[i]);
+                hb.freeb[b0 + i] = std::move(part.freeb[i]);
+            }
+            // every page but the last pass's has its boxes: their crops go through the recogniser's conv stack (queued behind the
+            // detector on `stream`) while the last pass's CCL + host geometry run -- that stretch would otherwise leave the card idle
+            if (early_on && subs.size() >= 2 && k + 2 == subs.size() && pp.rotation_info[0] == 0 && ctx->crnn_loaded)
+                rec_early_begin(ctx, dev_gray, b0 + nb, B, H, W, hb, pp, early);
+        }
+        HIPCHK(hipEventSynchronize(ctx->det_t1));   // the detector's end, not the stream's: the early recogniser part may be running behind it
+        float det_ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&det_ms, ctx->det_t0, ctx->det_t1));
+        ctx->times[0] = det_ms;          // GPU span of the detector; box extraction (times[1], times[2]) overlaps it except for the last sub-batch
+        (void)t0;
+        std::vector<BoxJob> jobs;
+        std::vector<int> off;
+        recognize_impl(ctx, dev_gray, B, H, W, hb, pp, jobs, off, &early);
+        prof_collect(ctx);
+        *out = export_result(B, jobs, off);
+        ctx->times[7] = (float)ms_since(t_all);
+    });
+}
+
+int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w) {
+    return guarded(ctx, [&] {
+        if (H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad image shape");
+        const int dh = (int)(H * 1.5), dw = (int)(W * 1.5);
+        if (out_h) *out_h = dh;
+        if (out_w) *out_w = dw;
+        if (!dev_out) return;
+        if (!dev_bgr) fail(BBOCR_ERR_ARG, "null device pointer");
+        if (dh < 16 || dw < 16) fail(BBOCR_ERR_ARG, "image too small for the 8x8 CLAHE tile grid");
+        preprocess_book_cover_impl(ctx, dev_bgr, H, W, dev_out, dh, dw);
+    });
+}
+
+void bbocr_free_boxlist(bbocr_boxlist* b) {
+    if (!b) return;
+    free(b->poly_off); free(b->polys); free(b->hori_off); free(b->hori); free(b->free_off); free(b->free_q);
+    free(b);
+}
+
+void bbocr_free_result(bbocr_result* r) {
+    if (!r) return;
+    free(r->box_off); free(r->quads); free(r->is_free); free(r->text_off); free(r->text_idx); free(r->conf);
+    free(r);
+}
+
+int bbocr_set_profiling(bbocr_ctx* ctx, int on) {
+    if (!ctx) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    for (int g = 0; g < 2; ++g) { ctx->prof_ms[g] = 0; ctx->prof_flops[g] = 0; ctx->prof_launches[g] = 0; }
+    return BBOCR_OK;
+}
+
+int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches) {
+    if (!ctx || group < 0 || group > 1) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ms) *ms = ctx->prof_ms[group];
+    if (flops) *flops = ctx->prof_flops[group];
+    if (launches) *launches = ctx->prof_launches[group];
+    return BBOCR_OK;
+}
+
+int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n) {
+    if (!ctx || !ms || n <= 0) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = ctx->times[i];
+    return BBOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------- host-only geometry (no GPU needed)
+
+}  // extern "C"

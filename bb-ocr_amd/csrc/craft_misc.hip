@@ -176,11 +176,12 @@ hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W
 }
 
 // ------------------------------------------------------------------------------------------------ gray
-// cv2 BGR2GRAY fixed point applied to channels as given (upstream applies it to whatever 3-channel array it holds).
+// cv2 BGR2GRAY applied to channels as given (upstream applies it to whatever 3-channel array it holds): OpenCV 4's 15-bit fixed
+// point (R 9798, G 19235, B 3735, round to nearest; pinned by the reference's stored pre-processing outputs, tests/golden/legacy_preprocess).
 __global__ void __launch_bounds__(256) gray_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t npix) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const int c0 = rgb[i * 3], c1 = rgb[i * 3 + 1], c2 = rgb[i * 3 + 2];
-        gray[i] = (uint8_t)((c2 * 4899 + c1 * 9617 + c0 * 1868 + (1 << 13)) >> 14);
+        gray[i] = (uint8_t)((c2 * 9798 + c1 * 19235 + c0 * 3735 + (1 << 14)) >> 15);
     }
 }
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {

@@ -1,0 +1,319 @@
+// Internal header of libbbocr: context, small host helpers and the functions the translation units share.
+// Translation units: weights.cpp (BN folding, MFMA packing), detector.cpp (CRAFT forward, box extraction), recognizer.cpp (crops,
+// CRNN, CTC), preprocess.cpp (the f2 chain), abi.cpp (context + pipeline entry points of include/bbocr.h), abi_ops.cpp (stage-level
+// entry points used by the parity tests).
+#pragma once
+#include "../../include/bbocr.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "boxpost.h"
+#include "common.h"
+#include "kernels.h"
+
+
+using clk = std::chrono::steady_clock;
+static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct StatusError {
+    int code;
+    std::string msg;
+};
+[[noreturn]] inline void fail(int code, const std::string& m) { throw StatusError{code, m}; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) fail(BBOCR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+struct DevBuf {   // growable device buffer, freed with its owner (the context)
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc(&p, n));
+        cap = n;
+    }
+    void ensure_keep(size_t n, size_t used) {   // grow, keeping the first `used` bytes (waits for the device: the old buffer may be in use)
+        if (n <= cap) return;
+        void* q = nullptr;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMalloc(&q, n));
+        if (p && used) HIPCHK(hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice));
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinBuf {   // growable pinned host buffer: the source of truly asynchronous H2D copies (a pageable source makes hipMemcpyAsync wait
+                  // for the stream first, which stalls the host exactly where it should be queueing work behind a running kernel)
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) { HIPCHK(hipDeviceSynchronize()); (void)hipHostFree(p); }     // a queued copy may still read the old buffer
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
+        cap = n;
+    }
+};
+
+struct Arena {   // bump allocator over one device buffer; a dry pass sizes it, the real pass carves it
+    DevBuf buf;
+    size_t off = 0;
+    bool dry = true;
+    void begin(bool d) { off = 0; dry = d; }
+    template <typename T> T* alloc(size_t count) {
+        off = align_up(off, 256);
+        T* r = dry ? nullptr : (T*)((char*)buf.p + off);
+        off += count * sizeof(T);
+        return r;
+    }
+};
+
+struct Act {   // bf16 NHWC activation
+    uint16_t* p;
+    int N, H, W, C;
+};
+
+
+
+struct bbocr_ctx {
+    bbocr_config cfg{};
+    hipStream_t stream = nullptr;
+    DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
+    unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
+    int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
+    hipStream_t cur = nullptr;                // stream the layer helpers launch on
+    hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
+    std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
+    hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
+    hipEvent_t det_t0 = nullptr, det_t1 = nullptr;   // detector span on `stream` (the host is busy with boxes meanwhile)
+    std::mutex mu;
+    std::string err;
+    float times[8] = {0};
+
+    // ---- optional per-launch timing of the conv_mfma kernel (HIP events on this context's stream)
+    struct ProfRec { hipEvent_t e0, e1; double flops; int group; };
+    int profiling = 0;                        // 0 off, 1 = time the detector's conv launches (group 0), 2 = also the recogniser's
+    int prof_group = 0;                     // 0 = detector, 1 = recogniser
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
+    long long prof_launches[2] = {0, 0};
+
+    // ---- detector
+    bool craft_loaded = false;
+    uint16_t* c11_w = nullptr;
+    uint16_t* c11_wf = nullptr;               // conv1_1 weights in the layout of the producer fused into conv1_2
+    float* c11_b = nullptr;
+    ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
+    ConvPlan up1a, up1b, up2b, up3b, up4b, cls0, cls2, cls4;
+    // U-net 1x1 layers over cat[up(y), skip], split by linearity: upNy = the columns of y (no bias, run at y's resolution),
+    // upNs = the columns of the skip tensor (+ bias), whose epilogue adds the 2x bilinear up-sampling of upNy's output
+    ConvPlan up2y, up2s, up3y, up3s, up4y, up4s;
+    float* cls_tail = nullptr;   // b1[16] w2[32] b2[2]
+    uint16_t* cls_tail_frag = nullptr;   // conv_cls.6 weight as an MFMA A fragment
+    // ---- recogniser
+    bool crnn_loaded = false;
+    float* r0_wb = nullptr;      // w[9][32] (tap-major) b[32]
+    ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
+    uint16_t* whh[2] = {nullptr, nullptr};
+    std::vector<void*> owned;    // every hipMalloc'd weight block
+
+    void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
+    Arena arena;
+    DevBuf heat, gray, resized;
+    DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
+    DevBuf crop_desc, crop_scratch, crop_hscratch, crop_wscratch, crop_luts, crop_hist;
+    DevBuf ctc_idx, ctc_pmax, ctc_out_idx, ctc_out, ctc_probs, crop_desc2;
+    PinBuf desc_pin, desc_pin2;               // staging of crop_desc / crop_desc2 uploads
+    PinBuf ctc_pin;                           // CTC results land here (pinned: the 1.7 MB D2H copy of a 64-page pass runs at link speed)
+    DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
+};
+
+// ------------------------------------------------------------------------------------------------ shared types
+struct TensorMap {
+    std::unordered_map<std::string, const bbocr_tensor_desc*> m;
+    TensorMap(const bbocr_tensor_desc* d, int n) {
+        for (int i = 0; i < n; ++i) {
+            std::string k = d[i].name ? d[i].name : "";
+            if (k.rfind("module.", 0) == 0) k = k.substr(7);
+            m[k] = &d[i];
+        }
+    }
+    const float* get(const std::string& name, size_t numel, bool required = true) const {
+        auto it = m.find(name);
+        if (it == m.end()) {
+            if (required) fail(BBOCR_ERR_WEIGHTS, "missing tensor '" + name + "'");
+            return nullptr;
+        }
+        size_t n = 1;
+        for (int i = 0; i < it->second->ndim; ++i) n *= (size_t)it->second->shape[i];
+        if (n != numel || !it->second->data)
+            fail(BBOCR_ERR_WEIGHTS, "tensor '" + name + "' has " + std::to_string(n) + " elements, expected " + std::to_string(numel));
+        return it->second->data;
+    }
+};
+
+struct RgbSource { const uint8_t* rgb; int Himg, Wimg; };   // conv1_2 with conv1_1 fused in: a0 then only carries the canvas shape
+
+struct DetDims {
+    int H32, W32, h, w, th, tw;
+    double ratio;
+};
+
+struct HostBoxes {
+    std::vector<std::vector<std::array<int, 8>>> polys;
+    std::vector<std::vector<std::array<int, 4>>> hori;
+    std::vector<std::vector<std::array<double, 8>>> freeb;
+};
+
+struct BoxJob {            // one box to recognise
+    int img;
+    bool is_free;
+    double quad[8];        // reported corners
+    CropDesc d;
+    std::vector<int> text;
+    double conf = 0.0;
+};
+
+struct RecChunk {
+    int imgW, T, first, n;   // descriptors [first, first+n) share the padded width imgW
+    size_t row0;             // first pooled row of the chunk in the pass's sequence tensors
+};
+
+struct RecPart {
+    std::vector<CropDesc> descs;
+    std::vector<int> order;          // position in the pass's result vectors for each descriptor
+    std::vector<RecChunk> chunks;
+    size_t rows = 0, cols = 0;       // pooled rows / wide-image columns of this part
+    bool any_warp = false, any_tall = false;
+};
+
+struct RecRun {
+    std::vector<int> tiles, seqs, seq_k;   // int4 {row0, n, T, 0} per LSTM workgroup; int2 {row0, T} and result position per sequence
+    size_t rows = 0;
+    int n_results = 0;
+};
+
+struct RecEarly {
+    bool active = false;
+    int pages = 0;
+    std::vector<BoxJob> jobs;
+    std::vector<int> box_off;        // [pages + 1]
+    size_t a_total = 0, w_total = 0; // crop scratch consumed by those jobs
+    RecPart part;
+};
+
+constexpr int REC_GAP = 4;
+
+// ------------------------------------------------------------------------------------------------ shared functions
+template <typename T> inline T* upload(bbocr_ctx* c, const std::vector<T>& v) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, v.size() * sizeof(T)));
+    c->owned.push_back(d);
+    HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return (T*)d;
+}
+
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil);
+void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b);
+void free_weights(bbocr_ctx* c);
+void load_craft(bbocr_ctx* c, const TensorMap& tm);
+void load_crnn(bbocr_ctx* c, const TensorMap& tm);
+void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a);
+void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out, int out_cs, int cout_store, bool out_f32, const Act* addup = nullptr);
+void prof_collect(bbocr_ctx* c);
+Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, int store);
+Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, bool relu_out, int store, int mode, bool pool_relu, Act* full, const RgbSource* rgb = nullptr);
+Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, int ph, int pw, bool relu_in);
+DetDims det_dims(int H, int W, int canvas, double mag);
+void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bbocr_params& p, float* heat, const std::function<void(int, int)>& after_sub = nullptr);
+void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double ratio, const bbocr_params& p, HostBoxes& hb, hipStream_t st);
+bbocr_boxlist* export_boxes(const HostBoxes& hb);
+void import_boxes(const bbocr_boxlist* bl, HostBoxes& hb);
+bool plan_horizontal(const std::array<int, 4>& box, int img, int H, int W, BoxJob& j);
+bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j);
+void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_t* v_out);
+void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, int ntiles, float* logits);
+double percentile_u8(const unsigned int* hist, size_t n, double q);
+void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, RecEarly& e);
+void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, std::vector<BoxJob>& jobs, std::vector<int>& box_off, RecEarly* early = nullptr);
+bbocr_result* export_result(int B, const std::vector<BoxJob>& jobs, const std::vector<int>& box_off);
+void pil_blend_lut(int in1, float alpha, uint8_t lut[256]);
+void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw);
+unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma);
+void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit);
+void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent, int threshold);
+void preprocess_book_cover_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, uint8_t* out, int dh, int dw);
+
+// bbocr.h promises that a call returns with its own work finished -- also when it fails half-way: kernels already queued may still
+// read caller-owned inputs / write caller-owned outputs, and host vectors that were async-copy targets die during unwinding
+inline void guarded_drain(bbocr_ctx* ctx) {
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipGetLastError();
+    for (auto& r : ctx->prof_recs) { ctx->prof_pool.push_back(r.e0); ctx->prof_pool.push_back(r.e1); }
+    ctx->prof_recs.clear();
+}
+
+// every ABI entry point runs inside guarded(): device selected, context locked, exceptions mapped to status codes
+template <typename F> inline int guarded(bbocr_ctx* ctx, F&& f) {
+    if (!ctx) return BBOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    try {
+        hipError_t e = hipSetDevice(ctx->cfg.device);
+        if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        ctx->cur = ctx->stream;
+        // the library runs on its own non-blocking streams: what the caller queued on the default stream (torch's) -- fills of
+        // output buffers, input copies -- must be complete before our kernels touch the same memory
+        e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("default stream: ") + hipGetErrorString(e));
+        f();
+        return BBOCR_OK;
+    } catch (const StatusError& se) {
+        ctx->err = se.msg;
+        guarded_drain(ctx);
+        return se.code;
+    } catch (const std::exception& ex) {
+        ctx->err = ex.what();
+        guarded_drain(ctx);
+        return BBOCR_ERR_INTERNAL;
+    } catch (...) {
+        ctx->err = "unknown failure";
+        guarded_drain(ctx);
+        return BBOCR_ERR_INTERNAL;
+    }
+}

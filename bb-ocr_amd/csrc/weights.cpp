@@ -1,0 +1,184 @@
+// Weight tables: eval-mode BatchNorm folded into the convolutions, bf16 rounding, MFMA fragment packing (easyocr Reader.__init__ / get_detector / get_recognizer).
+#include "ctx.h"
+
+// ------------------------------------------------------------------------------------------------ weights
+
+// conv (+ optional BatchNorm in eval mode) -> folded fp32 weight [Cout][Cin][K] and bias [Cout]
+static void fold_conv(const TensorMap& tm, const std::string& conv, const std::string& bn, int Cout, int Cin, int K, std::vector<float>& w,
+                      std::vector<float>& b) {
+    const size_t per = (size_t)Cin * K;
+    const float* cw = tm.get(conv + ".weight", (size_t)Cout * per);
+    const float* cb = tm.get(conv + ".bias", (size_t)Cout, false);
+    w.assign(cw, cw + (size_t)Cout * per);
+    b.assign(Cout, 0.f);
+    if (cb) std::copy(cb, cb + Cout, b.begin());
+    if (!bn.empty()) {
+        const float* g = tm.get(bn + ".weight", Cout);
+        const float* be = tm.get(bn + ".bias", Cout);
+        const float* mu = tm.get(bn + ".running_mean", Cout);
+        const float* var = tm.get(bn + ".running_var", Cout);
+        for (int o = 0; o < Cout; ++o) {
+            const float sc = g[o] / std::sqrt(var[o] + 1e-5f);
+            for (size_t i = 0; i < per; ++i) w[(size_t)o * per + i] *= sc;
+            b[o] = (b[o] - mu[o]) * sc + be[o];
+        }
+    }
+}
+
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil) {
+    ConvPlan p;
+    p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad_h = pad; p.pad_w = pad; p.dil = dil;
+    p.Cin_pad = cdiv(Cin, 32) * 32;
+    p.BN = conv_plan_bn(Cout);
+    p.Cout_pad = cdiv(Cout, p.BN) * p.BN;
+    return p;
+}
+
+void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b) {
+    std::vector<uint16_t> pk(conv_packed_elems(p));
+    pack_conv_weights(p, w.data(), pk.data());
+    std::vector<float> bp(p.Cout_pad, 0.f);
+    std::copy(b.begin(), b.end(), bp.begin());
+    p.d_w = upload(c, pk);
+    p.d_b = upload(c, bp);
+}
+
+// 1x1 conv over a channel concat [y (Cy) | skip (Cs)], BN folded, split into the two column blocks
+static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, ConvPlan& ps, const std::string& conv, const std::string& bn, int Cy,
+                           int Cs, int Cout) {
+    std::vector<float> w, b;
+    fold_conv(tm, conv, bn, Cout, Cy + Cs, 1, w, b);
+    std::vector<float> wy((size_t)Cout * Cy), ws((size_t)Cout * Cs), zero(Cout, 0.f);
+    for (int o = 0; o < Cout; ++o) {
+        std::copy(w.begin() + (size_t)o * (Cy + Cs), w.begin() + (size_t)o * (Cy + Cs) + Cy, wy.begin() + (size_t)o * Cy);
+        std::copy(w.begin() + (size_t)o * (Cy + Cs) + Cy, w.begin() + (size_t)(o + 1) * (Cy + Cs), ws.begin() + (size_t)o * Cs);
+    }
+    py = make_plan(Cy, Cout, 1, 1, 0, 1);
+    upload_plan(c, py, wy, zero);
+    ps = make_plan(Cs, Cout, 1, 1, 0, 1);
+    upload_plan(c, ps, ws, b);
+}
+
+static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std::string& conv, const std::string& bn, int Cin, int Cout,
+                       int K, int pad, int dil) {
+    p = make_plan(Cin, Cout, K, K, pad, dil);
+    std::vector<float> w, b;
+    fold_conv(tm, conv, bn, Cout, Cin, K * K, w, b);
+    upload_plan(c, p, w, b);
+}
+
+void free_weights(bbocr_ctx* c) {
+    for (void* p : c->owned) (void)hipFree(p);
+    c->owned.clear();
+    c->craft_loaded = c->crnn_loaded = false;
+}
+
+void load_craft(bbocr_ctx* c, const TensorMap& tm) {
+    {
+        std::vector<float> w, b;
+        fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);
+        std::vector<uint16_t> pk(2 * 4 * 64 * 8);
+        pack_conv1_1_weights(w.data(), pk.data());
+        c->c11_w = upload(c, pk);
+        pack_conv1_1_weights_fused(w.data(), pk.data());
+        c->c11_wf = upload(c, pk);
+        c->c11_b = upload(c, b);
+    }
+    load_layer(c, tm, c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1);
+    load_layer(c, tm, c->conv2_1, "basenet.slice1.7", "basenet.slice1.8", 64, 128, 3, 1, 1);
+    load_layer(c, tm, c->conv2_2, "basenet.slice1.10", "basenet.slice1.11", 128, 128, 3, 1, 1);
+    load_layer(c, tm, c->conv3_1, "basenet.slice2.14", "basenet.slice2.15", 128, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv3_2, "basenet.slice2.17", "basenet.slice2.18", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv3_3, "basenet.slice3.20", "basenet.slice3.21", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv4_1, "basenet.slice3.24", "basenet.slice3.25", 256, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv4_2, "basenet.slice3.27", "basenet.slice3.28", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv4_3, "basenet.slice4.30", "basenet.slice4.31", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1);
+    load_layer(c, tm, c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6);
+    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1);
+    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1);
+    load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1);
+    load_split_1x1(c, tm, c->up2y, c->up2s, "upconv2.conv.0", "upconv2.conv.1", 256, 512, 256);
+    load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1);
+    load_split_1x1(c, tm, c->up3y, c->up3s, "upconv3.conv.0", "upconv3.conv.1", 128, 256, 128);
+    load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1);
+    load_split_1x1(c, tm, c->up4y, c->up4s, "upconv4.conv.0", "upconv4.conv.1", 64, 128, 64);
+    load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
+    load_layer(c, tm, c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1);
+    {
+        const float* w1 = tm.get("conv_cls.6.weight", 256);
+        const float* b1 = tm.get("conv_cls.6.bias", 16);
+        const float* w2 = tm.get("conv_cls.8.weight", 32);
+        const float* b2 = tm.get("conv_cls.8.bias", 2);
+        std::vector<float> t(50);
+        std::copy(b1, b1 + 16, t.begin());
+        std::copy(w2, w2 + 32, t.begin() + 16);
+        std::copy(b2, b2 + 2, t.begin() + 48);
+        c->cls_tail = upload(c, t);
+        std::vector<uint16_t> fr(64 * 8);
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int o = l & 15, k = 8 * (l >> 4) + j;
+                fr[l * 8 + j] = f32_to_bf16_host(k < 16 ? w1[o * 16 + k] : 0.f);
+            }
+        c->cls_tail_frag = upload(c, fr);
+    }
+    c->craft_loaded = true;
+}
+
+void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
+    const std::string fe = "FeatureExtraction.ConvNet.";
+    {
+        std::vector<float> t(32 * 9 + 32);
+        const float* w = tm.get(fe + "0.weight", 32 * 9);
+        const float* b = tm.get(fe + "0.bias", 32);
+        for (int co = 0; co < 32; ++co)                       // tap-major [9][32]: the kernel reads channel PAIRS of one tap (packed FMA)
+            for (int tap = 0; tap < 9; ++tap) t[tap * 32 + co] = w[co * 9 + tap];
+        std::copy(b, b + 32, t.begin() + 288);
+        c->r0_wb = upload(c, t);
+    }
+    load_layer(c, tm, c->r1, fe + "3", "", 32, 64, 3, 1, 1);
+    load_layer(c, tm, c->r2, fe + "6", "", 64, 128, 3, 1, 1);
+    load_layer(c, tm, c->r3, fe + "8", "", 128, 128, 3, 1, 1);
+    load_layer(c, tm, c->r4, fe + "11", fe + "12", 128, 256, 3, 1, 1);
+    load_layer(c, tm, c->r5, fe + "14", fe + "15", 256, 256, 3, 1, 1);
+    load_layer(c, tm, c->r6, fe + "18", "", 256, 256, 2, 0, 1);
+    for (int l = 0; l < 2; ++l) {
+        const std::string sm = "SequenceModeling." + std::to_string(l) + ".";
+        // input projection of both directions as one 1x1 conv with the channel permutation the LSTM kernel reads
+        std::vector<float> w((size_t)2048 * 256), b(2048);
+        for (int d = 0; d < 2; ++d) {
+            const std::string sfx = d ? "_reverse" : "";
+            const float* wih = tm.get(sm + "rnn.weight_ih_l0" + sfx, (size_t)1024 * 256);
+            const float* bih = tm.get(sm + "rnn.bias_ih_l0" + sfx, 1024);
+            const float* bhh = tm.get(sm + "rnn.bias_hh_l0" + sfx, 1024);
+            for (int g = 0; g < 4; ++g)
+                for (int u = 0; u < 256; ++u) {
+                    const int src = g * 256 + u, dst = lstm8_xproj_channel(d, g, u);
+                    std::copy(wih + (size_t)src * 256, wih + (size_t)src * 256 + 256, w.begin() + (size_t)dst * 256);
+                    b[dst] = bih[src] + bhh[src];
+                }
+        }
+        c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1);
+        upload_plan(c, c->xproj[l], w, b);
+        const float* hf = tm.get(sm + "rnn.weight_hh_l0", (size_t)1024 * 256);
+        const float* hb = tm.get(sm + "rnn.weight_hh_l0_reverse", (size_t)1024 * 256);
+        std::vector<uint16_t> pk(lstm_whh_packed_elems());
+        pack_lstm_whh8(hf, hb, pk.data());
+        c->whh[l] = upload(c, pk);
+        std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
+        std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);
+        c->lin[l] = make_plan(512, 256, 1, 1, 0, 1);
+        upload_plan(c, c->lin[l], lw, lb);
+    }
+    {
+        std::vector<float> pw(tm.get("Prediction.weight", (size_t)97 * 256), tm.get("Prediction.weight", (size_t)97 * 256) + 97 * 256);
+        std::vector<float> pb(tm.get("Prediction.bias", 97), tm.get("Prediction.bias", 97) + 97);
+        c->pred = make_plan(256, 97, 1, 1, 0, 1);
+        upload_plan(c, c->pred, pw, pb);
+    }
+    c->crnn_loaded = true;
+}

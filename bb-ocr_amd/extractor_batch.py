@@ -24,7 +24,7 @@ def ocr_input_image(image_path, image_index=None):
     produce for the file easyocr is given: (RGB uint8 [H,W,3], gray uint8 [H,W])."""
     from PIL import Image
 
-    from .reader import reformat_input
+    from .reader import decode_file, reformat_input
 
     cover = image_index is None or image_index == 0
     max_dim = 1600 if cover else 2400
@@ -35,8 +35,7 @@ def ocr_input_image(image_path, image_index=None):
             img.thumbnail((max_dim, max_dim))
             buf = io.BytesIO()
             img.save(buf, format="JPEG", quality=(90 if cover else 95))
-            pil = Image.open(io.BytesIO(buf.getvalue()))          # what easyocr's loader sees: a JPEG file on disk
-            return np.ascontiguousarray(pil.convert("RGB")), np.ascontiguousarray(pil.convert("L"))
+            return decode_file(buf.getvalue())                    # what easyocr's loader sees: a JPEG file on disk
     except Exception:
         pass                                                      # :511-514: any failure falls back to the original file
     return reformat_input(os.fspath(image_path))

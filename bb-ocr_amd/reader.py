@@ -38,9 +38,39 @@ _DET_KW = ("min_size", "text_threshold", "low_text", "link_threshold", "canvas_s
 
 
 def _gray_bgr2gray(a: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(a, COLOR_BGR2GRAY) fixed point on the channels as given."""
+    """cv2.cvtColor(a, COLOR_BGR2GRAY) on the channels as given: OpenCV 4's 15-bit fixed point (R 9798, G 19235, B 3735,
+    round to nearest) -- pinned by the reference's stored pre-processing outputs (tests/golden/legacy_preprocess)."""
     a = a.astype(np.int32)
-    return ((a[..., 2] * 4899 + a[..., 1] * 9617 + a[..., 0] * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((a[..., 2] * 9798 + a[..., 1] * 19235 + a[..., 0] * 3735 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def decode_file(source):
+    """What upstream's path branch holds after ``cv2.imread(path, IMREAD_GRAYSCALE)`` + ``loadImage(path)`` (skimage -> RGB):
+    ``(rgb uint8 HWC, gray uint8 HW)``.  ONE stated rule for the gray plane, by container:
+      * JPEG: libjpeg decodes straight to its Y plane (``out_color_space = JCS_GRAYSCALE``) -- PIL's ``draft('L')`` asks
+        libjpeg for exactly that, so no RGB -> gray formula is involved;
+      * single-channel files (PNG/TIFF/... mode L, 1): the stored samples;
+      * every other colour file (OpenCV's PNG reader: ``png_set_rgb_to_gray(1, 0.299, 0.587)``): libpng's truncating
+        15-bit sum ``(9797 R + 19234 G + 3737 B) >> 15``, grey pixels unchanged.
+    ``source`` is a path or a bytes object holding the file."""
+    from PIL import Image
+
+    def _open():
+        return Image.open(io.BytesIO(source)) if isinstance(source, (bytes, bytearray)) else Image.open(os.path.expanduser(str(source)))
+
+    pil = _open()
+    rgb = np.ascontiguousarray(pil.convert("RGB"))
+    if pil.format in ("JPEG", "MPO") and pil.mode in ("RGB", "YCbCr"):
+        y = _open()
+        y.draft("L", y.size)
+        grey = np.ascontiguousarray(y.convert("L"))
+        if grey.shape != rgb.shape[:2]:                      # draft() may not scale; keep the rule total
+            grey = np.ascontiguousarray(pil.convert("L"))
+        return rgb, grey
+    if pil.mode in ("L", "1"):
+        return rgb, np.ascontiguousarray(pil.convert("L"))
+    a = rgb.astype(np.int32)
+    return rgb, ((a[..., 0] * 9797 + a[..., 1] * 19234 + a[..., 2] * 3737) >> 15).astype(np.uint8)
 
 
 def reformat_input(image, device_gray=False):
@@ -53,8 +83,7 @@ def reformat_input(image, device_gray=False):
     _gray = (lambda a: None) if device_gray else _gray_bgr2gray
 
     if isinstance(image, (str, os.PathLike)):
-        pil = Image.open(os.path.expanduser(str(image)))
-        return np.ascontiguousarray(pil.convert("RGB")), np.ascontiguousarray(pil.convert("L"))
+        return decode_file(image)
     if isinstance(image, (bytes, bytearray)):
         pil = Image.open(io.BytesIO(bytes(image)))
         img = np.ascontiguousarray(pil.convert("RGB"))
@@ -262,6 +291,23 @@ class Reader:
         self._torch.cuda.current_stream(self.device_index).synchronize()
         return t
 
+    def _dev_u8(self, t, name, ndim, shape=None):
+        """A tensor about to cross the C ABI as a raw pointer: anything but a contiguous uint8 tensor of the expected shape on THIS
+        context's device would be an out-of-bounds device access (a GPU fault kills the process; the reference relies on exceptions,
+        enhanced_extractor.py:529-531) -> ValueError before the ctypes call."""
+        torch = self._torch
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"{name}: expected a torch uint8 device tensor, got {type(t).__name__}")
+        if not t.is_cuda or t.device.index != self.device_index:
+            raise ValueError(f"{name}: tensor lives on {t.device}, this Reader runs on {self.device}")
+        if t.dtype != torch.uint8:
+            raise ValueError(f"{name}: dtype must be uint8, got {t.dtype}")
+        if t.ndim != ndim or (shape is not None and tuple(t.shape) != tuple(shape)) or min(t.shape) <= 0:
+            raise ValueError(f"{name}: bad shape {tuple(t.shape)}" + (f", expected {tuple(shape)}" if shape is not None else f" ({ndim}-D expected)"))
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        return t
+
     def _collect(self, res_p, detail=1):
         """bbocr_result -> per-page [(bbox, text, conf)] (upstream's list shape); numpy views instead of per-element ctypes access."""
         r = res_p.contents
@@ -310,7 +356,12 @@ class Reader:
     # -- easyocr surface ---------------------------------------------------------------
     def readtext_device(self, rgb_dev, gray_dev=None, **kw):
         """Batch entry for pages already resident in HBM: uint8 torch tensors [B,H,W,3] (+ optional [B,H,W])."""
-        B, H, W, _ = rgb_dev.shape
+        self._dev_u8(rgb_dev, "rgb", 4)
+        B, H, W, ch = rgb_dev.shape
+        if ch != 3:
+            raise ValueError(f"rgb: last dimension must be 3, got {ch}")
+        if gray_dev is not None:
+            self._dev_u8(gray_dev, "gray", 3, (B, H, W))
         p = self._params(kw)
         res = C.POINTER(_lib.bbocr_result)()
         gp = C.c_void_p(gray_dev.data_ptr()) if gray_dev is not None else C.c_void_p(None)
@@ -366,6 +417,8 @@ class Reader:
         rgb = np.asarray(rgb)
         if rgb.dtype != np.uint8 or rgb.ndim != 4 or rgb.shape[3] != 3:
             raise ValueError("readtext_arrays expects uint8 [B,H,W,3]")
+        if gray is not None and (np.asarray(gray).dtype != np.uint8 or np.asarray(gray).shape != rgb.shape[:3]):
+            raise ValueError("readtext_arrays: gray must be uint8 [B,H,W] matching rgb")
         return self.readtext_device(self._to_dev(rgb), self._to_dev(np.asarray(gray)) if gray is not None else None, **kw)
 
     def detect(self, img, min_size=20, text_threshold=0.7, low_text=0.4, link_threshold=0.4, canvas_size=2560, mag_ratio=1.0,
@@ -406,7 +459,10 @@ class Reader:
 
     def heatmap_device(self, rgb_dev, **kw):
         """uint8 [B,H,W,3] device tensor -> (fp32 [B,h,w,2] device tensor, ratio)."""
-        B, H, W, _ = rgb_dev.shape
+        self._dev_u8(rgb_dev, "rgb", 4)
+        B, H, W, ch = rgb_dev.shape
+        if ch != 3:
+            raise ValueError(f"rgb: last dimension must be 3, got {ch}")
         _, _, h, w, ratio = self.detect_dims(H, W, kw.get("canvas_size", 2560), kw.get("mag_ratio", 1.0))
         heat = self._torch.empty((B, h, w, 2), dtype=self._torch.float32, device=self.device)
         p = self._params(kw)
@@ -415,6 +471,10 @@ class Reader:
 
     def boxes_from_heatmap(self, heat_dev, ratio, **kw):
         """fp32 [B,h,w,2] device tensor -> (horizontal lists, free lists, polys) per page."""
+        torch = self._torch
+        if (not isinstance(heat_dev, torch.Tensor) or not heat_dev.is_cuda or heat_dev.device.index != self.device_index
+                or heat_dev.dtype != torch.float32 or heat_dev.ndim != 4 or heat_dev.shape[3] != 2 or not heat_dev.is_contiguous()):
+            raise ValueError(f"heat-map: expected a contiguous float32 [B,h,w,2] tensor on {self.device}")
         B, h, w, _ = heat_dev.shape
         p = self._params(kw)
         bl = C.POINTER(_lib.bbocr_boxlist)()
@@ -430,7 +490,10 @@ class Reader:
         return hori, free, polys
 
     def recognize_device(self, gray_dev, horizontal_lists, free_lists, **kw):
+        self._dev_u8(gray_dev, "gray", 3)
         B, H, W = gray_dev.shape
+        if len(horizontal_lists) != B or len(free_lists) != B:
+            raise ValueError("one horizontal list and one free list per page")
         n_h = [len(x) for x in horizontal_lists]
         n_f = [len(x) for x in free_lists]
         hoff = (C.c_int * (B + 1))(*np.concatenate([[0], np.cumsum(n_h)]).astype(int).tolist())

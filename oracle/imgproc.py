@@ -18,8 +18,8 @@ import numpy as np
 INTER_RESIZE_COEF_BITS = 11
 INTER_RESIZE_COEF_SCALE = 1 << INTER_RESIZE_COEF_BITS
 
-# cv2 fixed-point luma weights (yuv_shift = 14)
-_R2Y, _G2Y, _B2Y, _YUV_SHIFT = 4899, 9617, 1868, 14
+# cv2 fixed-point luma weights, OpenCV 4 (gray_shift = 15; pinned by tests/golden/legacy_preprocess)
+_R2Y, _G2Y, _B2Y, _YUV_SHIFT = 9798, 19235, 3735, 15
 
 
 def gray_from_3ch(img: np.ndarray, order: str = "bgr") -> np.ndarray:
@@ -33,20 +33,37 @@ def gray_from_3ch(img: np.ndarray, order: str = "bgr") -> np.ndarray:
     return y.astype(np.uint8)
 
 
+def decode_file(path):
+    """cv2.imread(path, IMREAD_GRAYSCALE) + loadImage(path) restated on PIL, ONE rule per container (re-verify list):
+    JPEG -> libjpeg's own Y plane (grfmt_jpeg.cpp: out_color_space = JCS_GRAYSCALE; PIL's draft('L') requests the same);
+    single-channel files -> stored samples; other colour files -> libpng's rgb_to_gray as OpenCV configures it
+    (grfmt_png.cpp: png_set_rgb_to_gray(1, 0.299, 0.587) -> coefficients 9797 / 19234 / 3737, truncating >> 15)."""
+    from PIL import Image
+
+    pil = Image.open(path)
+    rgb = np.asarray(pil.convert("RGB"))
+    if pil.format in ("JPEG", "MPO") and pil.mode in ("RGB", "YCbCr"):
+        y = Image.open(path)
+        y.draft("L", y.size)
+        grey = np.asarray(y.convert("L"))
+        return rgb, (grey if grey.shape == rgb.shape[:2] else np.asarray(pil.convert("L")))
+    if pil.mode in ("L", "1"):
+        return rgb, np.asarray(pil.convert("L"))
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return rgb, ((r * 9797 + g * 19234 + b * 3737) >> 15).astype(np.uint8)
+
+
 def reformat_input(image):
     """easyocr/utils.py::reformat_input -> (img RGB uint8 HWC, img_cv_grey uint8 HW).
 
-    File paths / bytes are decoded with PIL (cv2/skimage are absent); gray for
-    those inputs uses PIL's ``convert('L')``.  ndarray inputs follow upstream's
+    File paths / bytes are decoded with PIL (cv2/skimage are absent); the gray plane of
+    a path follows ``decode_file``'s per-container rule.  ndarray inputs follow upstream's
     channel rules exactly, including the BGR2GRAY-on-whatever-you-passed quirk.
     """
     from PIL import Image
 
     if isinstance(image, (str, os.PathLike)):
-        pil = Image.open(os.path.expanduser(str(image)))
-        grey = np.asarray(pil.convert("L"))
-        img = np.asarray(pil.convert("RGB"))
-        return img, grey
+        return decode_file(os.path.expanduser(str(image)))
     if isinstance(image, (bytes, bytearray)):
         pil = Image.open(io.BytesIO(bytes(image)))
         img = np.asarray(pil.convert("RGB"))

@@ -22,9 +22,10 @@ import numpy as np
 
 # ------------------------------------------------------------------------------------------------ cv2.cvtColor(BGR2GRAY), 8u
 def bgr2gray(bgr: np.ndarray) -> np.ndarray:
-    """cv2 color_rgb.simd.hpp RGB2Gray<uchar>: 14-bit fixed point, B 1868, G 9617, R 4899, round to nearest."""
+    """cv2 color_rgb.simd.hpp RGB2Gray<uchar>, OpenCV 4: 15-bit fixed point, B 3735, G 19235, R 9798, round to nearest.
+    (OpenCV 3's 14-bit 1868/9617/4899 does NOT reproduce the reference's stored outputs; the 15-bit one does.)"""
     b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 # ------------------------------------------------------------------------------------------------ cv2.resize INTER_CUBIC, 8u

@@ -216,6 +216,72 @@ def test_weight_descriptor_table(states):
     assert list(arr[i].shape) == [256, 256, 2, 2] and arr[i].ndim == 4
 
 
+def _save_upstream_checkpoints(directory, cs, rs):
+    """The two files easyocr downloads, in the two wrappings upstream checkpoints come in: the detector as a DataParallel
+    state-dict (``module.`` prefixes, ``num_batches_tracked`` entries), the recogniser wrapped in ``{"state_dict": ...}``."""
+    import torch
+
+    torch.save({("module." + k): torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(directory, "craft_mlt_25k.pth"))
+    torch.save({"state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}}, os.path.join(directory, "english_g2.pth"))
+
+
+def test_checkpoint_loader_round_trip(states, tmp_path):
+    """f1: ``Reader(model_storage_directory=...)``'s loader (weights.load_checkpoint_dir -> to_descs) on files with the upstream names:
+    same tensors as the in-memory states, prefix stripped by the library's table (api.cpp TensorMap), missing file -> FileNotFoundError."""
+    from bb_ocr_amd import weights
+
+    cs, rs = states
+    assert any(k.endswith("num_batches_tracked") for k in cs)
+    _save_upstream_checkpoints(str(tmp_path), cs, rs)
+    lc, lr = weights.load_checkpoint_dir(str(tmp_path))
+    assert set(lc) == {"module." + k for k in cs} and set(lr) == set(rs)
+    assert all(np.array_equal(lc["module." + k], v) for k, v in cs.items()) and all(np.array_equal(lr[k], v) for k, v in rs.items())
+    arr, keep = weights.to_descs(lc)
+    assert len(arr) == sum(not k.endswith("num_batches_tracked") for k in cs)
+    os.remove(os.path.join(str(tmp_path), "english_g2.pth"))
+    with pytest.raises(FileNotFoundError):
+        weights.load_checkpoint_dir(str(tmp_path))
+    import bb_ocr_amd
+
+    with pytest.raises(FileNotFoundError):
+        bb_ocr_amd.Reader._resolve_weights(None, str(tmp_path / "nowhere"))
+
+
+def test_path_inputs_follow_the_stated_gray_rule(tmp_path):
+    """a2 on the reference's only call pattern (a file path, enhanced_extractor.py:520): JPEG -> libjpeg's own Y plane, gray files ->
+    stored samples, colour PNG -> libpng's truncating 15-bit sum; product == oracle, and the colour array is the RGB decode."""
+    from PIL import Image
+
+    import bb_ocr_amd
+    from oracle import imgproc
+
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    rgb = np.kron(base, np.ones((8, 8, 1), dtype=np.uint8))            # 48 x 64, blocky so that JPEG keeps colours apart
+    jpg, png, gpng = (str(tmp_path / n) for n in ("c.jpg", "c.png", "g.png"))
+    Image.fromarray(rgb).save(jpg, quality=92)
+    Image.fromarray(rgb).save(png)
+    Image.fromarray(rgb[..., 1]).save(gpng)
+    for path in (jpg, png, gpng):
+        a, g = bb_ocr_amd.reformat_input(path)
+        ea, eg = imgproc.reformat_input(path)
+        assert np.array_equal(a, ea) and np.array_equal(g, eg) and g.shape == a.shape[:2]
+    a, g = bb_ocr_amd.reformat_input(jpg)
+    y = Image.open(jpg)
+    y.draft("L", y.size)
+    assert np.array_equal(g, np.asarray(y)) and np.array_equal(a, np.asarray(Image.open(jpg).convert("RGB")))
+    assert np.abs(g.astype(int) - imgproc.gray_from_3ch(a, "rgb").astype(int)).mean() < 1.0    # Y plane ~ luma of the decoded RGB (chroma clipping aside)
+    a, g = bb_ocr_amd.reformat_input(png)
+    r_, g_, b_ = (rgb[..., i].astype(np.int64) for i in range(3))
+    assert np.array_equal(a, rgb) and np.array_equal(g, ((r_ * 9797 + g_ * 19234 + b_ * 3737) >> 15).astype(np.uint8))
+    a, g = bb_ocr_amd.reformat_input(gpng)
+    assert np.array_equal(g, rgb[..., 1]) and np.array_equal(a, np.repeat(rgb[..., 1:2], 3, 2))
+    # OpenCV 4's BGR2GRAY (15-bit) on arrays: known answers
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [12, 200, 77], [255, 255, 255]]], dtype=np.uint8)   # channel 0 takes the "B" weight
+    assert imgproc.gray_from_3ch(px, "bgr").tolist() == [[29, 150, 76, 142, 255]]
+    assert bb_ocr_amd.reformat_input(px)[1].tolist() == [[29, 150, 76, 142, 255]]
+
+
 def test_shard_range_partitions_exactly():
     from bb_ocr_amd import dist
 

@@ -263,7 +263,7 @@ def test_preprocess_cv_stages_known_answers():
     flat = np.full((40, 56), 77, np.uint8)
     assert np.array_equal(pp.gaussian_blur3_u8(flat, 3.0), flat)
     assert np.array_equal(pp.resize_scale_u8(flat, 1.5), np.full((60, 84), 77, np.uint8))
-    assert np.array_equal(pp.bgr2gray(np.stack([flat, flat, flat], -1)), flat)          # 1868 + 9617 + 4899 = 2^14
+    assert np.array_equal(pp.bgr2gray(np.stack([flat, flat, flat], -1)), flat)          # 3735 + 19235 + 9798 = 2^15
     ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (30, 1))                       # slope 2 per source pixel
     up = pp.resize_scale_u8(ramp, 1.5).astype(np.int64)
     d = np.diff(up[10, 6:-6])
