@@ -30,6 +30,12 @@ class bbocr_params(C.Structure):
     ]
 
 
+class bbocr_preproc_params(C.Structure):
+    _fields_ = [("scale", C.c_double), ("blur_sigma", C.c_double), ("contrast", C.c_double), ("brightness", C.c_double),
+                ("clahe_clip", C.c_double), ("unsharp_radius", C.c_double), ("unsharp_percent", C.c_int), ("unsharp_threshold", C.c_int),
+                ("reserved", C.c_int * 4)]
+
+
 class bbocr_boxlist(C.Structure):
     _fields_ = [
         ("n_images", C.c_int), ("poly_off", C.POINTER(C.c_int)), ("polys", C.POINTER(C.c_int)),
@@ -78,6 +84,8 @@ PROTOTYPES = {
     "bbocr_op_crops": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_float,
                                  _vp, C.POINTER(C.c_int), C.c_int]),
     "bbocr_preprocess_book_cover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bbocr_preproc_defaults": (None, [C.POINTER(bbocr_preproc_params), C.c_int]),
+    "bbocr_preprocess_chain": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(bbocr_preproc_params), _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bbocr_op_preprocess_stage": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_double]),
 }
 

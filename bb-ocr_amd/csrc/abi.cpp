@@ -198,17 +198,38 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
     });
 }
 
-int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w) {
+void bbocr_preproc_defaults(bbocr_preproc_params* p, int legacy) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->scale = 1.5; p->unsharp_radius = 1.0; p->unsharp_threshold = 3;
+    if (legacy) { p->blur_sigma = 5.0; p->contrast = 1.3; p->brightness = 0.0; p->clahe_clip = 2.0; p->unsharp_percent = 20; }
+    else        { p->blur_sigma = 3.0; p->contrast = 1.9; p->brightness = 1.2; p->clahe_clip = 2.5; p->unsharp_percent = 30; }
+}
+
+int bbocr_preprocess_chain(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, const bbocr_preproc_params* p, uint8_t* dev_out, int* out_h,
+                           int* out_w) {
     return guarded(ctx, [&] {
+        bbocr_preproc_params q;
+        bbocr_preproc_defaults(&q, 0);
+        if (p) q = *p;
         if (H <= 0 || W <= 0) fail(BBOCR_ERR_ARG, "bad image shape");
-        const int dh = (int)(H * 1.5), dw = (int)(W * 1.5);
+        if (q.scale < 0 || q.blur_sigma < 0 || q.contrast < 0 || q.brightness < 0 || q.clahe_clip < 0 || q.unsharp_radius < 0 || q.unsharp_percent < 0)
+            fail(BBOCR_ERR_ARG, "negative pre-processing parameter");
+        const int dh = q.scale > 0 ? (int)(H * q.scale) : H, dw = q.scale > 0 ? (int)(W * q.scale) : W;
         if (out_h) *out_h = dh;
         if (out_w) *out_w = dw;
         if (!dev_out) return;
         if (!dev_bgr) fail(BBOCR_ERR_ARG, "null device pointer");
-        if (dh < 16 || dw < 16) fail(BBOCR_ERR_ARG, "image too small for the 8x8 CLAHE tile grid");
-        preprocess_book_cover_impl(ctx, dev_bgr, H, W, dev_out, dh, dw);
+        if (dh <= 0 || dw <= 0) fail(BBOCR_ERR_ARG, "image collapses to zero size");
+        if (q.clahe_clip > 0 && (dh < 16 || dw < 16)) fail(BBOCR_ERR_ARG, "image too small for the 8x8 CLAHE tile grid");
+        preprocess_chain_impl(ctx, dev_bgr, H, W, q, dev_out, dh, dw);
     });
+}
+
+int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w) {
+    bbocr_preproc_params q;
+    bbocr_preproc_defaults(&q, 0);
+    return bbocr_preprocess_chain(ctx, dev_bgr, H, W, &q, dev_out, out_h, out_w);
 }
 
 void bbocr_free_boxlist(bbocr_boxlist* b) {

@@ -39,6 +39,15 @@ int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src,
             ctx->pp_c.ensure(n);
             pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, (float)param, 30, 3);
             HIPCHK(hipStreamSynchronize(ctx->stream));
+        } else if (stage == 7) {
+            ctx->pp_b.ensure(n);
+            ctx->pp_c.ensure(n);
+            pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, 1.0f, (int)param, 3);
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        } else if (stage == 6) {
+            // cv2.cvtColor(BGR2GRAY) on an interleaved 3-channel plane [H,W,3] (the gray plane reformat_input derives from arrays)
+            HIPCHK(launch_gray(dev_src, dev_dst, n, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
         } else {
             fail(BBOCR_ERR_ARG, "unknown pre-processing stage");
         }

@@ -277,7 +277,7 @@ void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int
 unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma);
 void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit);
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent, int threshold);
-void preprocess_book_cover_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, uint8_t* out, int dh, int dw);
+void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const bbocr_preproc_params& q, uint8_t* out, int dh, int dw);
 
 // bbocr.h promises that a call returns with its own work finished -- also when it fails half-way: kernels already queued may still
 // read caller-owned inputs / write caller-owned outputs, and host vectors that were async-copy targets die during unwinding

@@ -3,32 +3,35 @@
 
 // ------------------------------------------------------------------------------------------------ pre-processing chain (f2)
 // Host-side constants of the chain, computed exactly like oracle/preprocess.py (float32 where the C sources use float).
-struct CubicAxis { std::vector<int> first; std::vector<short> coef; };
-static CubicAxis cubic_axis(int dst, int src) {   // imgproc resize.cpp: fx in float, cvFloor, interpolateCubic (A = -0.75), cvRound(c * 2048)
+// cv2.resize INTER_CUBIC through IPP (see preproc.hip::pp_resize_cubic_kernel and oracle/preprocess.py::_cubic_axis_exact): phase
+// t = n / (2 dst) exactly, weights as exact integers over K = 4 (2 dst)^3 and as correctly rounded doubles (both < 2^53)
+struct CubicAxis { std::vector<int> first; std::vector<double> wf; std::vector<long long> wi; unsigned long long K; };
+static CubicAxis cubic_axis(int dst, int src) {
+    if (dst <= 0 || dst >= 65536 || src <= 0 || src >= (1 << 24)) fail(BBOCR_ERR_ARG, "cubic resize: plane too large for the exact weight tables");
     CubicAxis a;
     a.first.resize(dst);
-    a.coef.resize((size_t)dst * 4);
-    const double scale = (double)src / (double)dst;
-    const float A = -0.75f;
+    a.wf.resize((size_t)dst * 4);
+    a.wi.resize((size_t)dst * 4);
+    const __int128 D = 2 * (__int128)dst;
+    const __int128 K = 4 * D * D * D;
+    a.K = (unsigned long long)K;
+    auto inner = [&](__int128 x) { return 5 * x * x * x - 9 * D * x * x + 4 * D * D * D; };                       // 4 D^3 ((A+2) t^3 - (A+3) t^2 + 1)
+    auto outer = [&](__int128 x) { return -3 * x * x * x + 15 * D * x * x - 24 * D * D * x + 12 * D * D * D; };    // 4 D^3 (A t^3 - 5A t^2 + 8A t - 4A)
     for (int d = 0; d < dst; ++d) {
-        float f = (float)(((double)d + 0.5) * scale - 0.5);
-        const int s = (int)std::floor(f);
-        f = f - (float)s;
-        float c[4];
-        const float x = f;
-        c[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
-        c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
-        c[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
-        c[3] = 1.f - c[0] - c[1] - c[2];
-        a.first[d] = s - 1;
+        const long long num = (2LL * d + 1) * src - dst;       // source coordinate = num / (2 dst)
+        long long s = num / (long long)D;
+        if (num < 0 && s * (long long)D != num) --s;           // floor
+        const __int128 n = num - s * (long long)D;
+        const __int128 c[4] = {outer(n + D), inner(n), inner(D - n), outer(2 * D - n)};
+        a.first[d] = (int)s - 1;
         for (int k = 0; k < 4; ++k) {
-            long v = std::lrint((double)c[k] * 2048.0);        // cvRound: half to even
-            a.coef[(size_t)d * 4 + k] = (short)std::max<long>(-32768, std::min<long>(32767, v));
+            a.wi[(size_t)d * 4 + k] = (long long)c[k];
+            a.wf[(size_t)d * 4 + k] = (double)(long long)c[k] / (double)a.K;
         }
     }
     return a;
 }
-static void gaussian_taps3(double sigma, int k[3]) {   // getGaussianKernelBitExact -> 8.8 fixed point, error diffusion (sum 256)
+void gaussian_taps3(double sigma, int k[3]) {   // getGaussianKernelBitExact -> 8.8 fixed point, error diffusion (sum 256)
     double v[3], tot = 0;
     for (int i = 0; i < 3; ++i) { v[i] = std::exp(-((double)(i - 1) * (i - 1)) / (2.0 * sigma * sigma)); tot += v[i]; }
     double err = 0;
@@ -57,18 +60,23 @@ static float pil_box_radius(float radius, int passes) {   // libImaging/BoxBlur.
 
 void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw) {
     const CubicAxis ax = cubic_axis(dw, W), ay = cubic_axis(dh, H);
-    const size_t bytes = (size_t)dw * 4 + (size_t)dw * 8 + (size_t)dh * 4 + (size_t)dh * 8;
+    const size_t nx = (size_t)dw, ny = (size_t)dh;
+    const size_t bytes = (nx + ny) * (4 * 8 + 4 * 8) + (nx + ny) * 4 + 64;
     c->pp_tab.ensure(bytes);
-    unsigned char* t = (unsigned char*)c->pp_tab.p;
-    int* x0 = (int*)t;                         t += (size_t)dw * 4;
-    int* y0 = (int*)t;                         t += (size_t)dh * 4;
-    short* cx = (short*)t;                     t += (size_t)dw * 8;
-    short* cy = (short*)t;
-    HIPCHK(hipMemcpyAsync(x0, ax.first.data(), (size_t)dw * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(y0, ay.first.data(), (size_t)dh * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(cx, ax.coef.data(), (size_t)dw * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(cy, ay.coef.data(), (size_t)dh * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, cx, y0, cy, c->stream));
+    unsigned char* t = (unsigned char*)c->pp_tab.p;       // 8-byte tables first (alignment), then the int tables
+    double* wx = (double*)t;        t += nx * 32;
+    double* wy = (double*)t;        t += ny * 32;
+    long long* ix = (long long*)t;  t += nx * 32;
+    long long* iy = (long long*)t;  t += ny * 32;
+    int* x0 = (int*)t;              t += nx * 4;
+    int* y0 = (int*)t;
+    HIPCHK(hipMemcpyAsync(wx, ax.wf.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(wy, ay.wf.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(ix, ax.wi.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(iy, ay.wi.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(x0, ax.first.data(), nx * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(y0, ay.first.data(), ny * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, ax.K, ay.K, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // the host tables must outlive the copies
 }
 // GaussianBlur 3x3; returns the sum of the output pixels (for the following Contrast step)
@@ -153,23 +161,73 @@ void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, ui
     HIPCHK(launch_pp_unsharp(src, cur, dst, (size_t)H * W, percent, threshold, c->stream));
 }
 
-void preprocess_book_cover_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, uint8_t* out, int dh, int dw) {
+void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const bbocr_preproc_params& q, uint8_t* out, int dh, int dw) {
     const size_t n = (size_t)dh * dw;
     c->pp_gray.ensure((size_t)H * W);
     c->pp_a.ensure(n);
     c->pp_b.ensure(n);
     c->pp_c.ensure(n);
-    uint8_t *g = (uint8_t*)c->pp_gray.p, *a = (uint8_t*)c->pp_a.p, *b = (uint8_t*)c->pp_b.p, *cc = (uint8_t*)c->pp_c.p;
+    uint8_t *g = (uint8_t*)c->pp_gray.p, *bufs[3] = {(uint8_t*)c->pp_a.p, (uint8_t*)c->pp_b.p, (uint8_t*)c->pp_c.p};
     HIPCHK(launch_gray(bgr, g, (size_t)H * W, c->stream));             // channels as given: B 3735, G 19235, R 9798 (>> 15) for cv2.imread's BGR
-    pp_resize(c, g, H, W, a, dh, dw);
-    const unsigned long long sum = pp_gauss(c, a, dh, dw, b, 3.0);
-    // ImageEnhance.Contrast(1.9) then Brightness(1.2): two pointwise maps, folded into one LUT in front of CLAHE
-    const int mean = (int)((double)sum / (double)n + 0.5);
-    uint8_t l1[256], l2[256], lut[256];
-    pil_blend_lut(mean, 1.9f, l1);
-    pil_blend_lut(0, 1.2f, l2);
-    for (int i = 0; i < 256; ++i) lut[i] = l2[l1[i]];
-    pp_clahe(c, b, dh, dw, lut, a, 2.5);
-    pp_unsharp(c, a, dh, dw, out, b, cc, 1.0f, 30, 3);
+    const uint8_t* cur = g;
+    int nb = 0;                                                        // next free plane of the three
+    auto next = [&]() { uint8_t* b = bufs[nb]; nb = (nb + 1) % 3; return b; };
+    if (q.scale > 0) {
+        uint8_t* d = next();
+        pp_resize(c, cur, H, W, d, dh, dw);
+        cur = d;
+    }
+    // the mean ImageEnhance.Contrast needs: the blur kernel sums its own output; without a blur stage the identity taps (0, 256, 0) do
+    unsigned long long sum = 0;
+    bool have_sum = false;
+    if (q.blur_sigma > 0) {
+        uint8_t* d = next();
+        sum = pp_gauss(c, cur, dh, dw, d, q.blur_sigma);
+        have_sum = true;
+        cur = d;
+    }
+    // the two PIL enhancers are pointwise: folded into one LUT, applied in front of CLAHE (or on their own when CLAHE is skipped)
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i;
+    bool have_lut = false;
+    if (q.contrast > 0) {
+        if (!have_sum) {
+            c->pp_tab.ensure(64);
+            HIPCHK(hipMemsetAsync(c->pp_tab.p, 0, 8, c->stream));
+            uint8_t* d = next();
+            HIPCHK(launch_pp_gauss3(cur, dh, dw, d, 0, 256, 0, (unsigned long long*)c->pp_tab.p, c->stream));
+            HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            cur = d;
+        }
+        uint8_t l1[256];
+        pil_blend_lut((int)((double)sum / (double)n + 0.5), (float)q.contrast, l1);
+        for (int i = 0; i < 256; ++i) lut[i] = l1[lut[i]];
+        have_lut = true;
+    }
+    if (q.brightness > 0) {
+        uint8_t l2[256];
+        pil_blend_lut(0, (float)q.brightness, l2);
+        for (int i = 0; i < 256; ++i) lut[i] = l2[lut[i]];
+        have_lut = true;
+    }
+    if (q.clahe_clip > 0) {
+        uint8_t* d = next();
+        pp_clahe(c, cur, dh, dw, have_lut ? lut : nullptr, d, q.clahe_clip);
+        cur = d;
+    } else if (have_lut) {
+        uint8_t* d = next();
+        c->pp_tab.ensure(512);
+        HIPCHK(hipMemcpyAsync((unsigned char*)c->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_pp_lut(cur, d, (const uint8_t*)c->pp_tab.p + 256, n, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        cur = d;
+    }
+    if (q.unsharp_percent > 0 && q.unsharp_radius > 0) {
+        uint8_t *t1 = next(), *t2 = next();                            // `cur` is the third plane
+        pp_unsharp(c, cur, dh, dw, out, t1, t2, (float)q.unsharp_radius, q.unsharp_percent, q.unsharp_threshold);
+    } else {
+        HIPCHK(hipMemcpyAsync(out, cur, n, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
 }

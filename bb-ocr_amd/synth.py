@@ -16,8 +16,12 @@ _WORDS = ("the quick brown fox jumps over lazy dog beyond frontier romance of ea
 
 
 def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_size: int = 24, word_gap: int = 16, line_pitch: int = 40,
-         margin: int = 48):
-    """-> (rgb uint8 [H,W,3], word boxes [(x0,y0,x1,y1,text)])."""
+         margin: int = 48, colour: bool = False):
+    """-> (rgb uint8 [H,W,3], word boxes [(x0,y0,x1,y1,text)]).
+
+    ``colour=True`` tints paper and ink (a per-page offset on the red and blue channels plus per-pixel chroma noise; the green
+    channel -- the one the designed detector reads -- keeps the grey page's values), so that R != G != B everywhere and the
+    gray plane (cv2 BGR2GRAY on the device) is a genuine three-channel mix."""
     from PIL import Image, ImageDraw, ImageFont
 
     rng = np.random.default_rng(seed)
@@ -51,7 +55,14 @@ def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_
     fg = 30.0 + rng.uniform(-10.0, 10.0, (height, width))
     g = np.where(m, fg, bg)
     g = np.clip(np.rint(g), 0, 255).astype(np.uint8)
-    return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)), words
+    if not colour:
+        return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)), words
+    crng = np.random.default_rng(seed + 7_000_003)          # own stream: the grey page of a seed does not change
+    paper = crng.integers(-28, 17, 2)                        # (red, blue) offsets: cream / bluish / greenish stock
+    ink = crng.integers(0, 60, 2)                            # dark blue / sepia ink
+    off = np.where(m[:, :, None], ink[None, None, :], paper[None, None, :]) + crng.integers(-3, 4, (height, width, 2))
+    rb = np.clip(g[:, :, None].astype(np.int64) + off, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.stack([rb[..., 0], g, rb[..., 1]], axis=2)), words
 
 
 def pages(n: int, seed0: int = 1234, **kw):

@@ -190,9 +190,28 @@ int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const 
  * INTER_CUBIC, GaussianBlur 3x3 sigma 3, PIL Contrast 1.9, PIL Brightness 1.2, CLAHE (clip 2.5, 8x8 tiles),
  * PIL UnsharpMask(radius 1, 30 %, threshold 3).  out_h / out_w receive the output size (pass dev_out = NULL to query it). */
 int bbocr_preprocess_book_cover(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, uint8_t* dev_out, int* out_h, int* out_w);
-/* the chain's stages one by one on a gray plane (parity tests): stage 0 = resize cubic to (dh, dw), 1 = GaussianBlur 3x3
+/* The same ImagePreprocessor stage sequence with its parameters spelled out (a stage whose parameter is 0 is skipped).
+ * bbocr_preproc_defaults(p, 0) = the pipeline_demo chain above; (p, 1) = the LEGACY chain of
+ * pipeline_components/img_to_json/ocr_testing/preprocessing/image_preprocessor.py:221-252 (sigma 5, contrast 1.3, no brightness
+ * step, CLAHE 2.0, unsharp 20 %) -- the one whose stored outputs (results/images/book*_preprocessed.png) pin the stages. */
+typedef struct bbocr_preproc_params {
+    double scale;           /* resize(scale_factor): new size int(H*s) x int(W*s), cv2.INTER_CUBIC */
+    double blur_sigma;      /* denoise(strength): cv2.GaussianBlur 3x3, sigma */
+    double contrast;        /* increase_contrast(factor): PIL ImageEnhance.Contrast */
+    double brightness;      /* increase_brightness(factor): PIL ImageEnhance.Brightness */
+    double clahe_clip;      /* clahe(clip_limit), 8x8 tiles */
+    double unsharp_radius;  /* sharpen: PIL UnsharpMask radius (1.0) */
+    int unsharp_percent;    /* int(amount * 100) */
+    int unsharp_threshold;  /* 3 */
+    int reserved[4];
+} bbocr_preproc_params;
+void bbocr_preproc_defaults(bbocr_preproc_params* p, int legacy);
+int bbocr_preprocess_chain(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, const bbocr_preproc_params* p, uint8_t* dev_out, int* out_h,
+                           int* out_w);
+/* the chain's stages one by one (parity tests): stage 0 = resize cubic of a gray plane to (dh, dw), 1 = GaussianBlur 3x3
  * sigma `param`, 2 = PIL Contrast `param`, 3 = PIL Brightness `param`, 4 = CLAHE clip `param` 8x8, 5 = PIL UnsharpMask
- * (radius `param`, 30 %, threshold 3).  Stages 1-5 keep the size (dh = H, dw = W). */
+ * (radius `param`, 30 %, threshold 3), 6 = cv2 BGR2GRAY of an interleaved [H,W,3] plane (the gray plane reformat_input derives from
+ * arrays), 7 = PIL UnsharpMask (radius 1, `param` %, threshold 3).  Stages 1-7 keep the size (dh = H, dw = W). */
 int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src, int H, int W, uint8_t* dev_dst, int dh, int dw, double param);
 
 #ifdef __cplusplus

@@ -6,10 +6,14 @@ Follows ``pipeline_demo/ocr_testing/preprocessing/image_preprocessor.py::preproc
 ``increase_brightness(1.2)`` (:85-99, PIL ImageEnhance.Brightness) -> ``clahe(2.5)`` (:48-56, cv2.createCLAHE 8x8 tiles) ->
 ``sharpen(0.3)`` (:101-115, PIL ImageFilter.UnsharpMask(radius 1, percent 30, threshold 3)).
 
-PARITY: the three PIL steps are pinned against Pillow itself (tests/test_oracle_cpu.py runs the real ImageEnhance / ImageFilter
-on the same arrays).  The three OpenCV steps are restated from OpenCV 4.10's published algorithms (imgproc: color_rgb, resize,
-smooth / fixedpoint, clahe) -- cv2 is absent offline, so they are **PARITY UNPINNED**: the integer (non-SIMD) resize path is
-restated; builds whose SIMD vertical cubic pass evaluates in float may differ by 1 in rare rounding ties.
+PARITY: PINNED by the reference's own stored vectors -- five (input PNG, pre-processed PNG) pairs of the LEGACY chain
+(pipeline_components/img_to_json/ocr_testing/preprocessing/image_preprocessor.py:221-252: same stage functions, parameters sigma 5,
+contrast 1.3, CLAHE 2.0, unsharp 20 %, no brightness step), committed under tests/golden/legacy_preprocess/ and replayed by
+tests/test_oracle_cpu.py::test_legacy_preprocess_fixtures: bit-exact on the smallest pair, <= 64 of 1.3 M pixels off on the others,
+all of them next to a cubic-resize value within 2e-5 of a rounding boundary (Intel IPP's float32 evaluation inside cv2.resize, see
+resize_cubic_u8).  That pins BGR2GRAY (OpenCV 4's 15-bit coefficients), the cubic resize (IPP semantics, not OpenCV's fixed-point
+path), GaussianBlur's 8.8 fixed-point kernel, CLAHE (clip / redistribute / LUT rounding / float blend) and, once more, the three
+PIL stages, which are also pinned against Pillow itself (tests/test_oracle_cpu.py runs the real ImageEnhance / ImageFilter).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
@@ -29,6 +33,82 @@ def bgr2gray(bgr: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ cv2.resize INTER_CUBIC, 8u
+# opencv-python wheels (x86-64, every platform) are built with Intel IPP, and cv::resize hands 8-bit INTER_CUBIC to
+# ippiResizeCubic_8u (B = 0, C = 0.75, i.e. the same A = -0.75 kernel; imgproc/src/resize.cpp::ipp_resize: only NEAREST, AREA and
+# 8-bit LINEAR are kept away from IPP) -- NOT to OpenCV's own 11-bit fixed-point HResizeCubic / VResizeCubic, which the round-1
+# oracle restated and which is ~10 % of pixels off the reference's stored outputs.  IPP evaluates the cubic in floating point;
+# what the reference's five stored (input, output) pairs pin (tests/golden/legacy_preprocess, tests/test_oracle_cpu.py) is:
+#   value = sum_j sum_i wy_j wx_i src[clamp(y0 + j), clamp(x0 + i)],  w = cubic convolution weights (A = -0.75) at the exact
+#   rational phase t = frac((d + 0.5) * src / dst - 0.5),  result = round-half-to-EVEN(value), borders replicated.
+# The restatement below computes exactly that mathematical value (float64, and exact integer arithmetic for the pixels whose
+# value is within 1e-9 of a rounding boundary).  IPP's float32 evaluation differs from it only on pixels whose exact value lies
+# within ~2e-5 of x.5 (<= 64 of 1.3 M pixels in the reference's fixtures, 0 on the smallest).
+_A_NUM, _A_DEN = -3, 4
+
+
+def _cubic_axis_exact(dst: int, src: int):
+    """Per destination index: first tap (floor - 1), the four weights as float64 and as exact integers over K = 4 (2 dst)^3."""
+    d = np.arange(dst, dtype=np.int64)
+    num = (2 * d + 1) * src - dst                       # f = num / (2 dst)
+    den = 2 * dst
+    s = num // den                                      # floor
+    n = num - s * den                                   # t = n / den in [0, 1)
+    K = 4 * den ** 3
+    no = n.astype(object)
+    D = den
+
+    def inner(x):                                       # 4 D^3 ((A + 2) x^3 - (A + 3) x^2 + 1), x = x / D, A = -3/4
+        return 5 * x ** 3 - 9 * D * x ** 2 + 4 * D ** 3
+
+    def outer(x):                                       # 4 D^3 (A x^3 - 5 A x^2 + 8 A x - 4 A)
+        return -3 * x ** 3 + 15 * D * x ** 2 - 24 * D * D * x + 12 * D ** 3
+
+    ci = np.stack([outer(no + D), inner(no), inner(D - no), outer(2 * D - no)], axis=-1)     # object ints, rows sum to K
+    cf = (ci / K).astype(np.float64)                    # big-int true division: correctly rounded doubles
+    return s - 1, cf, ci, K
+
+
+def _resize_cubic_value(src: np.ndarray, dw: int, dh: int):
+    H, W = src.shape
+    x0, cx, ix, KX = _cubic_axis_exact(dw, W)
+    y0, cy, iy, KY = _cubic_axis_exact(dh, H)
+    s = src.astype(np.float64)
+    cols = [np.clip(x0 + k, 0, W - 1) for k in range(4)]
+    rows = [np.clip(y0 + k, 0, H - 1) for k in range(4)]
+    hor = sum(s[:, cols[k]] * cx[:, k][None, :] for k in range(4))
+    val = sum(hor[rows[k], :] * cy[:, k][:, None] for k in range(4))
+    return val, (rows, cols, iy, ix, KX * KY)
+
+
+def resize_cubic_near_ties(src: np.ndarray, dw: int, dh: int, eps: float) -> np.ndarray:
+    """Mask of destination pixels whose exact bicubic value lies within ``eps`` of a rounding boundary (x.5): the only pixels on
+    which a float32 evaluation (Intel IPP inside cv2.resize) can differ from the exactly rounded value."""
+    val, _ = _resize_cubic_value(src, dw, dh)
+    return np.abs(val - np.floor(val) - 0.5) < eps
+
+
+def resize_cubic_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) for one 8-bit channel as the IPP-backed wheels compute it (see
+    above): exact bicubic (A = -0.75), replicated borders, round half to even."""
+    val, (rows, cols, iy, ix, D) = _resize_cubic_value(src, dw, dh)
+    out = np.rint(val)
+    fl = np.floor(val)
+    ys, xs = np.nonzero(np.abs(val - fl - 0.5) < 1e-9)          # decide these exactly: 2 ex <> (2 n + 1) KX KY
+    if ys.size:
+        si = src.astype(np.int64)
+        for y, x in zip(ys.tolist(), xs.tolist()):
+            ex = 0
+            for j in range(4):
+                row = si[rows[j][y]]
+                ex += int(iy[y, j]) * sum(int(ix[x, i]) * int(row[cols[i][x]]) for i in range(4))
+            n = int(fl[y, x])
+            c = 2 * ex - (2 * n + 1) * D
+            out[y, x] = n + 1 if c > 0 else (n if c < 0 else n + (n & 1))
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+# OpenCV's OWN 8-bit cubic path (imgproc/src/resize.cpp HResizeCubic / VResizeCubic, 11-bit coefficients), which builds WITHOUT
+# IPP (e.g. aarch64 wheels) run.  Kept as a named alternative: it is ~10 % of pixels off the reference's stored outputs.
 def _cubic_coeffs(x: np.ndarray) -> np.ndarray:
     """imgproc resize.cpp interpolateCubic, A = -0.75, evaluated in float32 like the C code."""
     A = np.float32(-0.75)
@@ -42,32 +122,23 @@ def _cubic_coeffs(x: np.ndarray) -> np.ndarray:
 
 
 def _cubic_axis(dst: int, src: int):
-    """Per destination index: first source tap (floor - 1) and the four 11-bit fixed-point coefficients (resize.cpp: fx in
-    float, cvFloor, saturate_cast<short>(coef * 2048) = round half to even)."""
     scale = float(src) / float(dst)
     d = np.arange(dst, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
     f = (f - s.astype(np.float32)).astype(np.float32)
-    co = np.rint(_cubic_coeffs(f).astype(np.float64) * 2048.0).astype(np.int64)   # cvRound: half to even
-    co = np.clip(co, -32768, 32767)
+    co = np.clip(np.rint(_cubic_coeffs(f).astype(np.float64) * 2048.0).astype(np.int64), -32768, 32767)   # cvRound: half to even
     return s - 1, co
 
 
-def resize_cubic_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
-    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) for one 8-bit channel: horizontal pass in int32 with
-    coefficients scaled by 2^11, vertical pass + FixedPtCast<int, uchar, 22> ((v + 2^21) >> 22, saturated); taps outside the
-    image are clamped to the border pixel."""
+def resize_cubic_fixedpoint_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """Non-IPP cv2.resize INTER_CUBIC, 8-bit: int32 horizontal pass with 2^11-scaled coefficients, vertical pass + (v + 2^21) >> 22."""
     H, W = src.shape
     x0, cx = _cubic_axis(dw, W)
     y0, cy = _cubic_axis(dh, H)
     s = src.astype(np.int64)
-    hor = np.zeros((H, dw), dtype=np.int64)
-    for k in range(4):
-        hor += s[:, np.clip(x0 + k, 0, W - 1)] * cx[:, k][None, :]
-    out = np.zeros((dh, dw), dtype=np.int64)
-    for k in range(4):
-        out += hor[np.clip(y0 + k, 0, H - 1), :] * cy[:, k][:, None]
+    hor = sum(s[:, np.clip(x0 + k, 0, W - 1)] * cx[:, k][None, :] for k in range(4))
+    out = sum(hor[np.clip(y0 + k, 0, H - 1), :] * cy[:, k][:, None] for k in range(4))
     return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
 
 
@@ -229,15 +300,37 @@ def pil_unsharp_L(img: np.ndarray, radius: float = 1.0, percent: int = 30, thres
 
 
 # ------------------------------------------------------------------------------------------------ the chain
-def preprocess_for_book_cover(bgr: np.ndarray) -> np.ndarray:
-    """image_preprocessor.py:147-160 on a decoded BGR page -> the 8-bit gray image the reference then saves / OCRs."""
+def preprocess_chain(bgr: np.ndarray, scale=1.5, blur_sigma=3.0, contrast=1.9, brightness=1.2, clahe_clip=2.5, unsharp_percent=30) -> np.ndarray:
+    """The ImagePreprocessor stage sequence both versions of preprocess_for_book_cover run (a stage whose parameter is 0 is skipped)."""
     g = bgr2gray(bgr)
-    g = resize_scale_u8(g, 1.5)
-    g = gaussian_blur3_u8(g, 3.0)
-    g = pil_contrast_L(g, 1.9)
-    g = pil_brightness_L(g, 1.2)
-    g = clahe_u8(g, 2.5, (8, 8))
-    return pil_unsharp_L(g, 1.0, 30, 3)
+    if scale:
+        g = resize_scale_u8(g, scale)
+    if blur_sigma:
+        g = gaussian_blur3_u8(g, blur_sigma)
+    if contrast:
+        g = pil_contrast_L(g, contrast)
+    if brightness:
+        g = pil_brightness_L(g, brightness)
+    if clahe_clip:
+        g = clahe_u8(g, clahe_clip, (8, 8))
+    if unsharp_percent:
+        g = pil_unsharp_L(g, 1.0, unsharp_percent, 3)
+    return g
+
+
+def preprocess_for_book_cover(bgr: np.ndarray) -> np.ndarray:
+    """pipeline_demo/ocr_testing/preprocessing/image_preprocessor.py:147-160 on a decoded BGR page -> the 8-bit gray image the
+    reference then saves / OCRs."""
+    return preprocess_chain(bgr, 1.5, 3.0, 1.9, 1.2, 2.5, 30)
+
+
+LEGACY = dict(scale=1.5, blur_sigma=5.0, contrast=1.3, brightness=0.0, clahe_clip=2.0, unsharp_percent=20)
+
+
+def preprocess_for_book_cover_legacy(bgr: np.ndarray) -> np.ndarray:
+    """pipeline_components/img_to_json/ocr_testing/preprocessing/image_preprocessor.py:221-252 (the version that produced the
+    reference's stored results/images/*_preprocessed.png): sigma 5, contrast 1.3, no brightness step, CLAHE 2.0, unsharp 20 %."""
+    return preprocess_chain(bgr, **LEGACY)
 
 
 STEPS = ["original", "grayscale", "resize(scale_factor=1.5)", "denoise(strength=3)", "increase_contrast(factor=1.9)",

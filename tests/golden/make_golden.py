@@ -5,7 +5,11 @@ Two kinds of data:
   * reference_pairs.json -- the (input image -> joined EasyOCR text) pairs the REFERENCE repo holds for this path
     (pipeline_components/img_to_json/ocr_testing/results/json/ocr_comparison_*.json:4-8).  They need
     the real craft_mlt_25k.pth / english_g2.pth and are replayed by tests/test_golden_replay.py when BBOCR_WEIGHTS_DIR is
-    set.  Two of the small input images are committed under ref_images/ (data files of the reference's own tests).
+    set.  The five pre-processed input images are committed under ref_images/ (data files of the reference's own tests).
+  * legacy_preprocess/book{1,2,4,5,6}.png -- the reference's pipeline_components/books/dataset/*.png, i.e. the INPUTS whose
+    stored outputs are ref_images/book*_preprocessed.png (legacy preprocess_for_book_cover, image_preprocessor.py:221-252):
+    five (input, output) vectors that pin the oracle's pre-processing stages (tests/test_oracle_cpu.py::test_legacy_preprocess_fixtures).
+    Copied, not generated: `cp` from /root/reference (see copy_reference_images below).
   * oracle_*.npz -- seeded input/output vectors of the CPU oracle (oracle/), so that (a) the oracle cannot drift
     silently and (b) the GPU tests can compare against fixed numbers.  PARITY UNPINNED against real EasyOCR: neither the
     package nor its weights exist offline.
@@ -24,12 +28,24 @@ REF_JSON = "/root/reference/pipeline_components/img_to_json/ocr_testing/results/
 PAIRS = {  # json name -> (input image relative to the reference root, committed copy or None)
     "ocr_comparison_IMG_9684.json": ("pipeline_demo/books/2a/IMG_9684.JPG", None),
     "ocr_comparison_IMG_9685.json": ("pipeline_demo/books/2a/IMG_9685.JPG", None),
-    "ocr_comparison_book1.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book1_preprocessed.png", None),
+    "ocr_comparison_book1.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book1_preprocessed.png", "ref_images/book1_preprocessed.png"),
     "ocr_comparison_book2.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book2_preprocessed.png", "ref_images/book2_preprocessed.png"),
     "ocr_comparison_book4.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book4_preprocessed.png", "ref_images/book4_preprocessed.png"),
-    "ocr_comparison_book5.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book5_preprocessed.png", None),
-    "ocr_comparison_book6.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book6_preprocessed.png", None),
+    "ocr_comparison_book5.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book5_preprocessed.png", "ref_images/book5_preprocessed.png"),
+    "ocr_comparison_book6.json": ("pipeline_components/img_to_json/ocr_testing/results/images/book6_preprocessed.png", "ref_images/book6_preprocessed.png"),
 }
+
+
+def copy_reference_images():
+    """Data files of the reference's own manual tests (inputs and stored outputs), copied verbatim."""
+    import shutil
+
+    root = "/root/reference/pipeline_components"
+    os.makedirs(os.path.join(HERE, "legacy_preprocess"), exist_ok=True)
+    for n in (1, 2, 4, 5, 6):
+        shutil.copyfile(f"{root}/books/dataset/book{n}.png", os.path.join(HERE, "legacy_preprocess", f"book{n}.png"))
+        shutil.copyfile(f"{root}/img_to_json/ocr_testing/results/images/book{n}_preprocessed.png",
+                        os.path.join(HERE, "ref_images", f"book{n}_preprocessed.png"))
 
 
 def reference_pairs():
@@ -97,6 +113,7 @@ def oracle_vectors():
 
 if __name__ == "__main__":
     if os.path.isdir(REF_JSON):
+        copy_reference_images()
         reference_pairs()
     oracle_vectors()
     print("golden vectors written to", HERE)

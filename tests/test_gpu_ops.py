@@ -207,9 +207,49 @@ def test_preprocess_chain_bit_exact_vs_oracle(reader):
             assert np.array_equal(stage(3, img, 1.2), pp.pil_brightness_L(img, 1.2))
             assert np.array_equal(stage(4, img, 2.5), pp.clahe_u8(img, 2.5, (8, 8)))
             assert np.array_equal(stage(5, img, 1.0), pp.pil_unsharp_L(img, 1.0, 30, 3))
+            assert np.array_equal(stage(7, img, 20), pp.pil_unsharp_L(img, 1.0, 20, 3))
+            assert np.array_equal(stage(1, img, 5.0), pp.gaussian_blur3_u8(img, 5.0))
+        # exact ties of the cubic resize (flat columns a, a, a+1, a+1 under the 1/2 phase): decided in 128-bit integers, half to even
+        ties = np.repeat(np.tile(np.array([30, 30, 30, 31, 31, 31], dtype=np.uint8), 20)[None, :], shape[0], axis=0)
+        assert pp.resize_cubic_near_ties(ties, 180, int(shape[0] * 1.5), 1e-9).mean() > 0.05
+        assert np.array_equal(stage(0, ties, 0, int(shape[0] * 1.5), 180), pp.resize_cubic_u8(ties, 180, int(shape[0] * 1.5)))
+        odd = rng.integers(0, 256, (shape[0], 97), dtype=np.uint8)                 # a size ratio that is not 3/2: general rational phases
+        assert np.array_equal(stage(0, odd, 0, shape[0] + 13, 131), pp.resize_cubic_u8(odd, 131, shape[0] + 13))
     # the whole chain on a rendered page (BGR) and on noise
     page = synth.page(77, width=640, height=400, lines=8, margin=24)[0][:, :, ::-1]
     for bgr in (np.ascontiguousarray(page), rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)):
         got, path, steps = dev_pp.preprocess_for_book_cover(bgr, reader=reader)
         assert path is None and steps == pp.STEPS
         assert np.array_equal(got, pp.preprocess_for_book_cover(bgr))
+        got, path, steps = dev_pp.preprocess_for_book_cover(bgr, reader=reader, legacy=True)
+        assert steps == dev_pp.LEGACY_STEPS and np.array_equal(got, pp.preprocess_for_book_cover_legacy(bgr))
+    # stages skipped through bbocr_preproc_params (parameter 0): every subset the chain's branches distinguish
+    bgr = rng.integers(0, 256, (96, 144, 3), dtype=np.uint8)
+    dev = torch.from_numpy(bgr).cuda()
+    for kw in (dict(scale=0.0), dict(blur_sigma=0.0), dict(contrast=0.0, brightness=0.0), dict(clahe_clip=0.0), dict(unsharp_percent=0),
+               dict(blur_sigma=0.0, clahe_clip=0.0), dict(scale=0.0, blur_sigma=0.0, contrast=0.0, brightness=0.0, clahe_clip=0.0, unsharp_percent=0)):
+        ref_kw = dict(scale=1.5, blur_sigma=3.0, contrast=1.9, brightness=1.2, clahe_clip=2.5, unsharp_percent=30)
+        ref_kw.update(kw)
+        assert np.array_equal(dev_pp.preprocess_bgr_device(reader, dev, **kw).cpu().numpy(), pp.preprocess_chain(bgr, **ref_kw)), kw
+
+
+@pytest.mark.parametrize("n", [2, 4, 5, 6, 1])
+def test_legacy_preprocess_fixtures_on_device(reader, n):
+    """f2 against the reference's own vectors (the -m gpu twin of tests/test_oracle_cpu.py::test_legacy_preprocess_fixtures): the device
+    chain with the legacy parameters is bit-identical to the oracle on the reference's five inputs, hence book2 is bit-exact against the
+    reference's stored output and the others differ from it on the same <= 64 near-tie pixels (Intel IPP's float32 cubic resize)."""
+    import os
+
+    from PIL import Image
+
+    from bb_ocr_amd import preprocess as dev_pp
+    from oracle import preprocess as pp
+    from test_oracle_cpu import LEGACY_RESIDUAL
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rgba = np.array(Image.open(os.path.join(here, "legacy_preprocess", f"book{n}.png")))
+    want = np.array(Image.open(os.path.join(here, "ref_images", f"book{n}_preprocessed.png")))
+    bgr = np.ascontiguousarray(rgba[..., 2::-1])
+    got = dev_pp.preprocess_bgr_device(reader, torch.from_numpy(bgr).cuda(), legacy=True).cpu().numpy()
+    assert np.array_equal(got, pp.preprocess_for_book_cover_legacy(bgr))
+    assert int((got != want).sum()) == LEGACY_RESIDUAL[n]

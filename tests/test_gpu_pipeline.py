@@ -117,6 +117,69 @@ def test_heatmap_random_weights_relative(reader):
     r.close()
 
 
+def test_colour_inputs_gray_plane_and_every_input_form(reader, oracle_reader, tmp_path):
+    """a2 on the device: (1) gray_kernel on genuinely coloured pixels, bit-exact against the oracle's cv2 BGR2GRAY (15-bit, channels as
+    given); (2) every input form reformat_input accepts -- RGB / RGBA / gray arrays, encoded bytes, a PIL image, JPEG and PNG paths --
+    gives exactly what the same page gives when the oracle's (colour array, gray plane) pair is handed to the device directly, i.e.
+    decode rule + device gray plane == oracle's reformat_input; (3) a coloured page end to end: boxes identical to the oracle's."""
+    import io
+
+    from PIL import Image
+
+    from bb_ocr_amd import synth
+    from oracle import imgproc
+
+    rng = np.random.default_rng(31)
+    for shape in ((37, 53, 3), (240, 321, 3), (1, 1, 3)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        src = torch.from_numpy(a).cuda()
+        dst = torch.empty(shape[:2], dtype=torch.uint8, device="cuda")
+        reader._check(reader._lib.bbocr_op_preprocess_stage(reader._h, 6, C.c_void_p(src.data_ptr()), shape[0], shape[1],
+                                                            C.c_void_p(dst.data_ptr()), shape[0], shape[1], 0.0))
+        assert np.array_equal(dst.cpu().numpy(), imgproc.gray_from_3ch(a, "bgr"))
+    page = synth.page(61, width=448, height=256, lines=5, margin=24, colour=True)[0]
+    assert (page[..., 0] != page[..., 1]).mean() > 0.9 and (page[..., 2] != page[..., 1]).mean() > 0.9
+    buf = io.BytesIO()
+    Image.fromarray(page).save(buf, format="PNG")
+    jpg, png = str(tmp_path / "p.jpg"), str(tmp_path / "p.png")
+    Image.fromarray(page).save(jpg, quality=95)
+    Image.fromarray(page).save(png)
+    rgba = np.dstack([page, np.full(page.shape[:2], 255, np.uint8)])
+    forms = {"rgb": page, "rgba": rgba, "gray": np.ascontiguousarray(page[..., 1]), "bytes": buf.getvalue(), "pil": Image.fromarray(page),
+             "jpeg path": jpg, "png path": png}
+    for name, x in forms.items():
+        ea, eg = imgproc.reformat_input(x)
+        want = reader.readtext_arrays(np.ascontiguousarray(ea)[None], np.ascontiguousarray(eg)[None])[0]
+        got = reader.readtext(x)
+        assert got == want, name
+        assert len(got) >= 4, name
+    got = reader.readtext(page)
+    want = oracle_reader.readtext(page)
+    assert [g[0] for g in got] == [[list(map(int, p)) for p in w[0]] for w in want]
+
+
+def test_reader_from_checkpoint_directory(states, reader, tmp_path):
+    """f1: Reader(model_storage_directory=...) reads craft_mlt_25k.pth / english_g2.pth (DataParallel ``module.`` prefixes and
+    num_batches_tracked entries; ``{"state_dict": ...}`` wrapping) and returns exactly what Reader(weights=(cs, rs)) returns."""
+    import os
+
+    import bb_ocr_amd
+    from bb_ocr_amd import synth
+
+    cs, rs = states
+    torch.save({("module." + k): torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(str(tmp_path), "craft_mlt_25k.pth"))
+    torch.save({"state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}}, os.path.join(str(tmp_path), "english_g2.pth"))
+    r2 = bb_ocr_amd.Reader(["en"], gpu=True, model_storage_directory=str(tmp_path))
+    try:
+        for seed in (5, 6):
+            img = synth.page(seed, width=384, height=256, lines=5, margin=24, colour=bool(seed & 1))[0]
+            assert r2.readtext(img) == reader.readtext(img)
+    finally:
+        r2.close()
+    with pytest.raises(FileNotFoundError):
+        bb_ocr_amd.Reader(["en"], gpu=True, model_storage_directory=str(tmp_path / "missing"))
+
+
 def test_detector_resize_path(reader, oracle_reader):
     """Page larger than canvas_size: cv2-style resize + zero canvas padding before the network."""
     from bb_ocr_amd import synth
@@ -312,6 +375,25 @@ def test_error_paths_raise(reader):
     with pytest.raises(ValueError):
         reader.readtext(np.zeros((64, 64, 3), dtype=np.uint8), rotation_info=[45])
     assert reader.readtext(np.full((64, 96, 3), 235, dtype=np.uint8)) == []      # blank page: no boxes, no error
+    # tensors that would become out-of-bounds device accesses behind the C ABI are refused in Python (never a GPU fault)
+    ok = torch.full((1, 64, 96, 3), 235, dtype=torch.uint8, device="cuda")
+    bad = [torch.zeros((1, 64, 96, 3), dtype=torch.uint8),                        # host tensor
+           torch.zeros((1, 64, 96, 3), dtype=torch.float32, device="cuda"),      # wrong dtype
+           torch.zeros((1, 64, 96, 4), dtype=torch.uint8, device="cuda"),        # wrong channel count
+           torch.zeros((1, 64, 192, 3), dtype=torch.uint8, device="cuda")[:, :, ::2],   # not contiguous
+           torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda"), np.zeros((1, 64, 96, 3), np.uint8)]
+    for t in bad:
+        with pytest.raises(ValueError):
+            reader.readtext_device(t)
+        with pytest.raises(ValueError):
+            reader.heatmap_device(t)
+    with pytest.raises(ValueError):
+        reader.readtext_device(ok, torch.zeros((1, 64, 95), dtype=torch.uint8, device="cuda"))   # gray plane of another shape
+    with pytest.raises(ValueError):
+        reader.recognize_device(torch.zeros((1, 64, 96), dtype=torch.uint8), [[]], [[]])
+    with pytest.raises(ValueError):
+        reader.boxes_from_heatmap(torch.zeros((1, 32, 48, 2), dtype=torch.float16, device="cuda"), 1.0)
+    assert reader.readtext_device(ok) == [[]]
 
 
 def test_hip_path_against_committed_golden(reader):

@@ -254,9 +254,51 @@ def test_preprocess_pil_stages_pinned_against_pillow():
                 assert np.array_equal(np.asarray(im.filter(ImageFilter.UnsharpMask(radius=r, percent=p, threshold=t))), pp.pil_unsharp_L(a, r, p, t))
 
 
+LEGACY_RESIDUAL = {1: 64, 2: 0, 4: 9, 5: 5, 6: 8}      # pixels (of 141 k ... 1.38 M) on which the oracle differs from the reference's stored output
+
+
+@pytest.mark.parametrize("n", [2, 4, 5, 6, 1])
+def test_legacy_preprocess_fixtures(n):
+    """PINS the oracle's pre-processing stages with the reference's own vectors: pipeline_components/books/dataset/book<n>.png ->
+    .../ocr_testing/results/images/book<n>_preprocessed.png, produced by the legacy preprocess_for_book_cover
+    (pipeline_components/img_to_json/ocr_testing/preprocessing/image_preprocessor.py:221-252: gray, x1.5 INTER_CUBIC, GaussianBlur 3x3
+    sigma 5, Contrast 1.3, CLAHE 2.0 8x8, UnsharpMask(1, 20 %, 3)).  book2 is bit-exact; on the others at most 64 of 1.4 M pixels
+    differ, by at most 4 grey levels, and EVERY one of them touches (Chebyshev distance <= 1) a cubic-resize pixel whose exact value is
+    within 5e-5 of a rounding boundary -- the float32 evaluation of Intel IPP's ippiResizeCubic_8u, which cv2.resize dispatches to and
+    whose operation order is not published; 0.08 % of the pixels are such near-ties, so the coincidence cannot be chance."""
+    from PIL import Image
+    from scipy import ndimage
+
+    from oracle import preprocess as pp
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rgba = np.array(Image.open(os.path.join(here, "legacy_preprocess", f"book{n}.png")))
+    want = np.array(Image.open(os.path.join(here, "ref_images", f"book{n}_preprocessed.png")))
+    assert rgba.shape[2] == 4 and (rgba[..., 3] == 255).all()          # cv2.imread (IMREAD_COLOR) drops an all-opaque alpha plane
+    bgr = np.ascontiguousarray(rgba[..., 2::-1])
+    got = pp.preprocess_for_book_cover_legacy(bgr)
+    assert got.shape == want.shape == (int(rgba.shape[0] * 1.5), int(rgba.shape[1] * 1.5))
+    bad = np.nonzero(got != want)
+    assert len(bad[0]) == LEGACY_RESIDUAL[n], len(bad[0])
+    if len(bad[0]):
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 4
+        g = pp.bgr2gray(bgr)
+        near = pp.resize_cubic_near_ties(g, want.shape[1], want.shape[0], 5e-5)
+        assert near.mean() < 2e-3
+        assert ndimage.distance_transform_cdt(~near, metric="chessboard")[bad].max() <= 1
+    # each restated stage matters: OpenCV 3's 14-bit gray weights or OpenCV's own fixed-point cubic path are far off the stored output
+    if n == 2:
+        b, g_, r = (bgr[..., i].astype(np.int64) for i in range(3))
+        g14 = ((b * 1868 + g_ * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+        rest = lambda x: pp.pil_unsharp_L(pp.clahe_u8(pp.pil_contrast_L(pp.gaussian_blur3_u8(x, 5.0), 1.3), 2.0, (8, 8)), 1.0, 20, 3)
+        assert (rest(pp.resize_scale_u8(g14, 1.5)) != want).sum() > 1000
+        assert (rest(pp.resize_cubic_fixedpoint_u8(pp.bgr2gray(bgr), want.shape[1], want.shape[0])) != want).sum() > 10000
+
+
 def test_preprocess_cv_stages_known_answers():
     """f2: properties the OpenCV stages must have whatever the build: constants are fixed points, the blur taps are the
-    published 8.8 kernel, cubic resize reproduces linear ramps away from the borders, CLAHE of a flat tile stays in range."""
+    published 8.8 kernel, cubic resize reproduces linear ramps away from the borders and rounds exact ties to even, CLAHE of a flat
+    tile stays in range."""
     from oracle import preprocess as pp
 
     assert pp.gaussian_kernel3_fixed(3.0) == [84, 88, 84] and sum(pp.gaussian_kernel3_fixed(0.8)) == 256
@@ -268,6 +310,12 @@ def test_preprocess_cv_stages_known_answers():
     up = pp.resize_scale_u8(ramp, 1.5).astype(np.int64)
     d = np.diff(up[10, 6:-6])
     assert d.min() >= 1 and d.max() <= 2 and abs(float(d.mean()) - 4.0 / 3.0) < 0.05   # cubic reproduces a linear ramp
+    # exact ties: taps (a, a, a+1, a+1) at phase 1/2 give a + 0.5 whatever the row phase -> the EVEN neighbour (30.5 -> 30, 31.5 -> 32)
+    for a, want in ((30, 30), (31, 32)):
+        cols = np.repeat(np.array([[a, a, a, a + 1, a + 1, a + 1, a + 1, a + 1]], dtype=np.uint8), 12, axis=0)
+        up2 = pp.resize_scale_u8(cols, 1.5)
+        assert up2.shape == (18, 12) and (up2[:, 4] == want).all()
+        assert pp.resize_cubic_near_ties(cols, 12, 18, 1e-9)[:, 4].all()
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (67, 91), dtype=np.uint8)                                # not a multiple of the 8x8 grid
     out = pp.clahe_u8(img, 2.5, (8, 8))
