@@ -39,6 +39,48 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {   // o
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
+// ---- element type of MFMA operands / stored activations: EL = 0 bf16 (default), EL = 1 IEEE fp16 (bbocr_config::precision >= 1).
+// Both are 16-bit sign-magnitude formats with the same MFMA shape (v_mfma_f32_16x16x32_{bf16,f16}), so the kernels differ only in
+// these conversions.  fp16 keeps 11 significand bits against bf16's 8 (8x smaller rounding steps) with a range of 6e-8 .. 65504.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+static inline uint16_t f32_to_f16_host(float f) {          // round to nearest even, subnormals and overflow to inf handled
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+static inline float f16_to_f32_host(uint16_t u) {
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+static inline uint16_t f32_to_el_host(int el, float f) { return el ? f32_to_f16_host(f) : f32_to_bf16_host(f); }
+static inline float el_to_f32_host(int el, uint16_t u) { return el ? f16_to_f32_host(u) : bf16_to_f32_host(u); }
+
+template <int EL> struct El;
+template <> struct El<0> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ f32x2_t unpack2(unsigned int q) { return (f32x2_t){__uint_as_float(q << 16), __uint_as_float(q & 0xffff0000u)}; }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return f32_to_bf16_bits(f); }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return bf16_bits_to_f32(h); }
+};
+template <> struct El<1> {
+    typedef f16x8 v8;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) {     // RNE (v_cvt_f16_f32 x2 / v_cvt_pk_f16_f32), never the RTZ pack
+        const f32x2_t v = {lo, hi};
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+    }
+    static __device__ __forceinline__ f32x2_t unpack2(unsigned int q) { return __builtin_convertvector(__builtin_bit_cast(f16x2_t, q), f32x2_t); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+};
+// max of 16-bit sign-magnitude floats without knowing which: x ^ ((x >> 15) & 0x7fff) is monotone as int16 (and its own inverse)
+__device__ __forceinline__ s16x8 sm16_key(s16x8 x) { return x ^ ((x >> 15) & (short)0x7fff); }
+
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical ids so
 // neighbouring tiles (same activation patch / same weight panel) share one L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -21,11 +21,19 @@
 #include <type_traits>
 #include <utility>
 
+// Timing-only ablations (BBOCR_CONV_DBG) and the per-tile s_memtime timeline (BBOCR_CONV_STAMPS) produce garbage results / extra
+// syncs: they exist in diagnostic builds only (make DIAG=1 -> -DBBOCR_DIAG), the shipped library has neither the branches nor the knobs.
+#ifdef BBOCR_DIAG
+#define CONV_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define CONV_DBG(a, bit) false
+#endif
+
 // ---- shared epilogue: bias (+ReLU) (+fused max-pool).  Lane (pixel pl, group g) holds, per 16-pixel fragment, 16 outputs
 // acc[j][r]; the cout permutation of pack_conv_weights maps them to cout = tile + wn*64 + (j>>1)*32 + g*8 + (j&1)*4 + r:
 // TWO runs of 8 contiguous couts, 32 apart, so that one store instruction writes, for every pixel, 64 contiguous bytes
 // (4 lane groups x 16 B) instead of four 16-byte pieces with gaps.  v[i], i = j*4+r: run h = i>>3, position i&7.
-template <int MF, bool ADDUP = false>
+template <int EL, int MF, bool ADDUP = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn, int fpr,
                                               int lane, int BN, int sub = 1, int sph = 0, int spw = 0) {
     const int g = lane >> 4, pl = lane & 15;
@@ -37,7 +45,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
         // MFMA.  a.tail = {b1[16], w2[32], b2[2]} fp32, a.tail_frag = W1 as an MFMA A fragment (row = out channel, k = in
         // channel, zero beyond 16).
         const float* tw = a.tail;
-        const bf16x8 w1f = *(const bf16x8*)(a.tail_frag + lane * 8);
+        const typename El<EL>::v8 w1f = *(const typename El<EL>::v8*)(a.tail_frag + lane * 8);
         float cb[8], b1r[4], w2a[4], w2b[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) cb[i] = a.bias[(g & 1) * 8 + i];
@@ -54,10 +62,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             for (int j = 0; j < 2; ++j) {
                 const float x0 = fmaxf(acc[f][j][0] + cb[j * 4 + 0], 0.f), x1 = fmaxf(acc[f][j][1] + cb[j * 4 + 1], 0.f);
                 const float x2 = fmaxf(acc[f][j][2] + cb[j * 4 + 2], 0.f), x3 = fmaxf(acc[f][j][3] + cb[j * 4 + 3], 0.f);
-                bb[2 * j] = g < 2 ? pack_bf16x2(x0, x1) : 0u;
-                bb[2 * j + 1] = g < 2 ? pack_bf16x2(x2, x3) : 0u;
+                bb[2 * j] = g < 2 ? El<EL>::pack2(x0, x1) : 0u;
+                bb[2 * j + 1] = g < 2 ? El<EL>::pack2(x2, x3) : 0u;
             }
-            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, __builtin_bit_cast(bf16x8, bb), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 d = El<EL>::mfma(w1f, __builtin_bit_cast(typename El<EL>::v8, bb), (f32x4){0.f, 0.f, 0.f, 0.f});
             float p0 = 0.f, p1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -73,6 +81,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
     }
     const bool run0 = cout0 < a.cout_store, run1 = cout0 + 32 < a.cout_store;
     if (!run0) return;
+    const float sc = a.acc_scale;       // 1 unless the packed weights carry a power-of-two scale (fma(x, 1, b) == x + b)
     float bs[16];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -89,10 +98,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
     const bool fullw = !a.out_f32 && nt * BN + wn * 64 + 64 <= a.cout_store;   // wave-uniform
     int spw_cur = spw;                                                         // x phase of the fragment row being stored
     auto pack_runs = [&](const float (&v)[16], u32x4& lo, u32x4& hi) {
-        lo = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        hi = (u32x4){pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+        lo = (u32x4){El<EL>::pack2(v[0], v[1]), El<EL>::pack2(v[2], v[3]), El<EL>::pack2(v[4], v[5]), El<EL>::pack2(v[6], v[7])};
+        hi = (u32x4){El<EL>::pack2(v[8], v[9]), El<EL>::pack2(v[10], v[11]), El<EL>::pack2(v[12], v[13]), El<EL>::pack2(v[14], v[15])};
     };
-    auto store_frag = [&](void* base, size_t row, int cs, int xb, int xlim, bool row_ok, const float (&v)[16], bool f32) {
+    auto store_frag_at = [&](void* base, size_t row, int cs, int xb, int xlim, bool row_ok, const float (&v)[16], bool f32, int coff) {
         if (fullw) {
             u32x4 lo, hi, dA, dB;
             pack_runs(v, lo, hi);
@@ -103,7 +112,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 // B: lanes pl >= 8 keep their run 1, lanes pl < 8 take run 0 of lane pl+8  -> pixels 8..15
                 dB[i] = (unsigned)__builtin_amdgcn_update_dpp((int)hi[i], (int)lo[i], 0x108 /*row_shl:8*/, 0xF, 0x3, false);
             }
-            const int co = cout0 + (pl >> 3) * 32;
+            const int co = cout0 + (pl >> 3) * 32 + coff;
             const int xA = (xb + (pl & 7)) * sub + spw_cur, xB = (xb + 8 + (pl & 7)) * sub + spw_cur;
             uint16_t* op = (uint16_t*)base + row + co;
             if (row_ok && xA < xlim) *(u32x4*)(op + (size_t)xA * cs) = dA;
@@ -123,10 +132,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
         } else {
             u32x4 lo, hi;
             pack_runs(v, lo, hi);
-            uint16_t* op = (uint16_t*)base + row + (size_t)x * cs + cout0;
+            uint16_t* op = (uint16_t*)base + row + (size_t)x * cs + cout0 + coff;
             *(u32x4*)(op) = lo;
             if (run1) *(u32x4*)(op + 32) = hi;
         }
+    };
+    // a.split_off (exact recogniser mode, fp16): v = hi + lo with hi = fp16(v), lo = fp16(v - hi): 22 significand bits in two fp16 tensors
+    auto split_hi_lo = [&](const float (&v)[16], float (&vh)[16], float (&vl)[16]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            vh[i] = El<EL>::to_f32(El<EL>::from_f32(v[i]));
+            vl[i] = v[i] - vh[i];
+        }
+    };
+    auto store_frag = [&](void* base, size_t row, int cs, int xb, int xlim, bool row_ok, const float (&v)[16], bool f32) {
+        if (a.split_off) {
+            float vh[16], vl[16];
+            split_hi_lo(v, vh, vl);
+            store_frag_at(base, row, cs, xb, xlim, row_ok, vh, false, 0);
+            store_frag_at(base, row, cs, xb, xlim, row_ok, vl, false, a.split_off);
+            return;
+        }
+        store_frag_at(base, row, cs, xb, xlim, row_ok, v, f32, 0);
     };
     if constexpr (ADDUP) {
         // 1x1 launch over the flattened N*up_H*up_W pixel axis whose epilogue adds up(z): F.interpolate(scale 2, bilinear,
@@ -165,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 G.q[h * 4 + 2] = *(const u32x4*)(z10 + h * 32); G.q[h * 4 + 3] = *(const u32x4*)(z11 + h * 32);
             }
         };
-        auto two = [](unsigned int q) { return (f32x2_t){__uint_as_float(q << 16), __uint_as_float(q & 0xffff0000u)}; };
+        auto two = [](unsigned int q) { return El<EL>::unpack2(q); };
         Gather G[2];
         issue(0, G[0]);
 #pragma unroll
@@ -213,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[f][j][r] + bs[j * 4 + r];
+                    float x = fmaf(acc[f][j][r], sc, bs[j * 4 + r]);
                     if (a.relu_out) x = fmaxf(x, 0.f);
                     v[j * 4 + r] = x;
                 }
@@ -238,7 +265,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x0 = acc[f][j][r] + bs[j * 4 + r], x1 = acc[f + FPR][j][r] + bs[j * 4 + r];
+                        float x0 = fmaf(acc[f][j][r], sc, bs[j * 4 + r]), x1 = fmaf(acc[f + FPR][j][r], sc, bs[j * 4 + r]);
                         if (a.relu_out) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
                         v0[j * 4 + r] = x0;
                         v1[j * 4 + r] = x1;
@@ -257,15 +284,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
                     for (int i = 0; i < 16; ++i)      // neighbour lane l^1 by DPP quad_perm [1,0,3,2]: one VALU op instead of a ds_bpermute
                         m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[i]), 0xB1, 0xF, 0xF, true)));
                     const int px = ox >> 1;
-                    u32x4 lo, hi;
-                    pack_runs(m, lo, hi);
-                    uint16_t* op = (uint16_t*)a.pool_out + prow + (size_t)px * a.pool_cs + cout0;
-                    if (fullw) {
-                        // both lanes of a pair hold the pooled pixel: the even one stores run 0, the odd one run 1 -> whole lines
-                        if (py < POH && px < POW) *(u32x4*)(op + (pl & 1) * 32) = (pl & 1) ? hi : lo;
-                    } else if (!(pl & 1) && py < POH && px < POW) {
-                        *(u32x4*)(op) = lo;
-                        if (run1) *(u32x4*)(op + 32) = hi;
+                    auto store_pooled = [&](const float (&mv)[16], int coff) {
+                        u32x4 lo, hi;
+                        pack_runs(mv, lo, hi);
+                        uint16_t* op = (uint16_t*)a.pool_out + prow + (size_t)px * a.pool_cs + cout0 + coff;
+                        if (fullw) {
+                            // both lanes of a pair hold the pooled pixel: the even one stores run 0, the odd one run 1 -> whole lines
+                            if (py < POH && px < POW) *(u32x4*)(op + (pl & 1) * 32) = (pl & 1) ? hi : lo;
+                        } else if (!(pl & 1) && py < POH && px < POW) {
+                            *(u32x4*)(op) = lo;
+                            if (run1) *(u32x4*)(op + 32) = hi;
+                        }
+                    };
+                    if (a.split_off) {
+                        float mh[16], ml[16];
+                        split_hi_lo(m, mh, ml);
+                        store_pooled(mh, 0);
+                        store_pooled(ml, a.split_off);
+                    } else {
+                        store_pooled(m, 0);
                     }
                 } else {
                     store_frag(a.pool_out, prow, a.pool_cs, xb, POW, py < POH, m, false);
@@ -280,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
 
 // Generic register-staged variant (any kernel size / dilation / pooling): 256-thread workgroups built for TWO co-resident
 // workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
-template <int WM, int WN, int MF, int PITER>
+template <int EL, int WM, int WN, int MF, int PITER>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     constexpr int WBUF = BN * 64;          // bytes of one weight k-step slice (BN couts x 32 k x 2 B)
@@ -341,7 +378,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
         for (int i = 0; i < PH; ++i) {
             const int sp = src_pix[part * PH + i];
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (sp >= 0 && !(a.dbg & 2)) v = *(const u32x4*)(src + (size_t)sp * cs + cb);   // dbg bit 2: timing-only ablation
+            if (sp >= 0 && !CONV_DBG(a, 2)) v = *(const u32x4*)(src + (size_t)sp * cs + cb);   // dbg bit 2: timing-only ablation
             pre[i] = v;
         }
     };
@@ -389,7 +426,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
     // ---- weight slice: LDS-DMA, LDS image == global image (fragment order), lane-linear
     const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
     auto issue_w = [&](int ks, int buf) {
-        if (a.dbg & 1) return;   // timing-only ablation (BBOCR_CONV_DBG): no weight DMA, results are garbage
+        if (CONV_DBG(a, 1)) return;   // timing-only ablation (diagnostic build, BBOCR_CONV_DBG): no weight DMA, results are garbage
 #pragma unroll
         for (int p0 = 0; p0 < WPIECES; p0 += NT) {
             if (p0 + wave * 64 < WPIECES) {
@@ -433,19 +470,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
                 if (more && a.ntaps >= 3) stage_patch_load(c + 1, tap);
                 if (ks + 1 < nk) issue_w(ks + 1, (ks + 1) & 1);
                 const unsigned char* wb = wbuf + (ks & 1) * WBUF + lane_w_off;
-                bf16x8 af[4];
+                typename El<EL>::v8 af[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+                for (int j = 0; j < 4; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
                 const unsigned char* pb = pbase + ((ky * a.PW + kx) * a.dil) * 16;
                 // all activation fragments are requested up front (MF ds_read_b128 in flight) so the LDS latency is paid
                 // once per k-step; left to itself hipcc serialises read -> lgkmcnt(0) -> 4 MFMAs per fragment
-                bf16x8 bq[MF];
+                typename El<EL>::v8 bq[MF];
 #pragma unroll
-                for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+                for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
                 }
                 // pin the order: every fragment read first, then the MFMA stream behind counted lgkmcnt waits
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
@@ -460,7 +497,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
         }
     }
 
-    conv_epilogue<MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
+    conv_epilogue<EL, MF>(a, acc, n, nt, oy0, ox0, wm, wn, fpr, lane, BN);
 }
 
 // ================================================================================================ 3x3, LDS-DMA staged
@@ -480,7 +517,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 // resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
 // NF (cout fragments a wave multiplies, 4 or 2): layers with <= 32 real couts in a 64-cout tile (up4b, conv_cls.0/.2/.4) skip the two
 // fragments that are pure padding (couts 32..63 of the tile, see the cout mapping of the epilogue) -- half the MFMAs, same results.
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -550,8 +587,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             spix[pb] = (py < a.PH && rowok && iy < a.H && lx >= 0 && ix < a.W) ? (g.n * a.H + iy) * a.W + ix : -1;
         }
     };
-    auto stamp = [&](int i) {   // diagnostic build of the tile timeline; a.stamps is null in production
+    auto stamp = [&](int i) {   // tile timeline: compiled in by -DBBOCR_DIAG only
+#ifdef BBOCR_DIAG
         if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + i] = __builtin_amdgcn_s_memtime();
+#endif
     };
     stamp(0);
     Geo cur;
@@ -635,18 +674,18 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
                     const uint8_t* q = rgb + ((size_t)(cur.n * a.rgb_H + iy) * a.rgb_W + ix) * 3;
                     r = (float)q[0]; g = (float)q[1]; b = (float)q[2];
                 }
-                v[0] = pack_bf16x2((r - m0) / s0, (g - m1) / s1);
-                v[1] = pack_bf16x2((b - m2) / s2, 0.f);
+                v[0] = El<EL>::pack2((r - m0) / s0, (g - m1) / s1);
+                v[1] = El<EL>::pack2((b - m2) / s2, 0.f);
             }
             rgbp[p] = v;
         }
         // conv1_1 weights as MFMA A fragments: K = tap*4 + channel padded to 64 (two k-steps), couts in the run order of the
         // epilogue mapping, so that a lane's 16 outputs are exactly one 16-byte slot of each 32-channel chunk of the patch image
-        bf16x8 w1[2][4];
+        typename El<EL>::v8 w1[2][4];
 #pragma unroll
         for (int ks1 = 0; ks1 < 2; ++ks1)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w1[ks1][j] = *(const bf16x8*)(a.c11_w + ((size_t)(ks1 * 4 + j) * 64 + lane) * 8);
+            for (int j = 0; j < 4; ++j) w1[ks1][j] = *(const typename El<EL>::v8*)(a.c11_w + ((size_t)(ks1 * 4 + j) * 64 + lane) * 8);
         const int g = lane >> 4, pl = lane & 15;
         float b1[16];
 #pragma unroll
@@ -667,9 +706,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
                 const int pc = pp < 324 ? py * 20 + px : 0;
                 const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
                 const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+                const typename El<EL>::v8 bfr = __builtin_bit_cast(typename El<EL>::v8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ks1][j], bfr, d[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) d[j] = El<EL>::mfma(w1[ks1][j], bfr, d[j]);
             }
             const int iy = cur.oy0 - 1 + py, ix = cur.ox0 - 1 + px;
             const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;     // else: conv1_2's own zero padding
@@ -681,7 +720,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
                     for (int i = 0; i < 4; ++i) {
                         const int k = h * 8 + i * 2;
                         const float x0 = fmaxf(d[k >> 2][k & 3] + b1[k], 0.f), x1 = fmaxf(d[(k + 1) >> 2][(k + 1) & 3] + b1[k + 1], 0.f);
-                        o[i] = inside ? pack_bf16x2(x0, x1) : 0u;
+                        o[i] = inside ? El<EL>::pack2(x0, x1) : 0u;
                     }
                     *(u32x4*)(pbuf + h * patch_bytes + (g * NP + pp) * 16) = o;
                 }
@@ -717,20 +756,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         constexpr int ky = tap / 3, kx = tap % 3;
         const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
         const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
-        bf16x8 af[NF], bq[MF];
+        typename El<EL>::v8 af[NF], bq[MF];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) af[j] = *(const bf16x8*)(wb + j * 1024);
+        for (int j = 0; j < NF; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
 #pragma unroll
-        for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(pb + frag_off[f]);
+        for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
         if ((c * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
             const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
+            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(typename El<EL>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
         }
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+            for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
@@ -741,9 +780,16 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
     chunk(std::false_type{}, a.nchunks - 1);
     stamp(2);
-    if (!(a.dbg & 8)) conv_epilogue<MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
-    else if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];   // dbg bit 8: timing-only ablation, no epilogue
+#ifdef BBOCR_DIAG
+    if (CONV_DBG(a, 8)) {   // timing-only ablation, no epilogue
+        if (acc[0][0][0] == 123.456f) *(float*)a.out = acc[MF - 1][3][3];
+        return;
+    }
+#endif
+    conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+#ifdef BBOCR_DIAG
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+#endif
 }
 
 // ================================================================================================ 1x1, LDS-DMA staged
@@ -752,7 +798,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 // BOTH operand tiles of k-step ks+RING-1 are issued by LDS-DMA at k-step ks (weights: lane-linear slice; activations: wave w
 // gathers channel group w of 256 consecutive pixels, 16 B per lane), and the barrier waits with the constant counted
 // vmcnt((RING-2) * DMAs-per-k-step).  No halo, so the tile is simply 256 consecutive pixels of N*H*W.
-template <int WM, int WN, int MF, int RING, bool ADDUP>
+template <int EL, int WM, int WN, int MF, int RING, bool ADDUP>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the activation tile");
@@ -814,32 +860,32 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const Conv
             issue(ks + RING - 1, sl);
         }
         const unsigned char* sb = smem + slot * SLOT;
-        bf16x8 af[4], bq[MF];
+        typename El<EL>::v8 af[4], bq[MF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(sb + lane_w_off + j * 1024);
+        for (int j = 0; j < 4; ++j) af[j] = *(const typename El<EL>::v8*)(sb + lane_w_off + j * 1024);
 #pragma unroll
-        for (int f = 0; f < MF; ++f) bq[f] = *(const bf16x8*)(sb + lane_p_off + f * 256);
+        for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(sb + lane_p_off + f * 256);
         if ((ks * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
             const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
+            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(typename El<EL>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
         }
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bq[f], acc[f][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
         // k-step ks+1 was issued RING-2 k-steps ago; while the pipeline is full exactly RING-2 later issues follow it
         if (ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 2) * (WPT + NPB)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         slot = slot + 1 == RING ? 0 : slot + 1;
     }
-    conv_epilogue<MF, ADDUP>(a, acc, 0, nt, 0, px0, wm, wn, 16, lane, BN);
+    conv_epilogue<EL, MF, ADDUP>(a, acc, 0, nt, 0, px0, wm, wn, 16, lane, BN);
 }
 
-template <int WM, int WN, int MF, bool ADDUP>
+template <int EL, int WM, int WN, int MF, bool ADDUP>
 static hipError_t launch_dma1x1_k(const ConvArgs& a, long long grid, hipStream_t s) {
     constexpr int RING = 3, NPX = WM * MF * 16;
-    auto k = conv1x1_dma_kernel<WM, WN, MF, RING, ADDUP>;
+    auto k = conv1x1_dma_kernel<EL, WM, WN, MF, RING, ADDUP>;
     const size_t smem = (size_t)RING * ((size_t)WN * 64 * 64 + (size_t)NPX * 64);
     static bool attr = false;
     if (!attr) {
@@ -851,7 +897,7 @@ static hipError_t launch_dma1x1_k(const ConvArgs& a, long long grid, hipStream_t
     return hipGetLastError();
 }
 
-template <int WM, int WN, int MF>
+template <int EL, int WM, int WN, int MF>
 static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
     constexpr int NPX = WM * MF * 16;
     const long long total = (long long)a.N * a.H * a.W;
@@ -861,7 +907,7 @@ static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
     const long long grid = (long long)a.tiles_x * a.ntiles_n;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     // the epilogue that adds an up-sampled tensor is its own instantiation: its register needs must not leak into the others
-    return a.addup ? launch_dma1x1_k<WM, WN, MF, true>(a, grid, s) : launch_dma1x1_k<WM, WN, MF, false>(a, grid, s);
+    return a.addup ? launch_dma1x1_k<EL, WM, WN, MF, true>(a, grid, s) : launch_dma1x1_k<EL, WM, WN, MF, false>(a, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -886,15 +932,15 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
                             const int cin = c * 32 + 8 * (l >> 4) + j;
                             float v = 0.f;
                             if (cout < p.Cout && cin < p.Cin) v = w[((size_t)cout * p.Cin + cin) * ntaps + tap];
-                            out[o++] = f32_to_bf16_host(v);
+                            out[o++] = f32_to_el_host(p.el, v);
                         }
                     }
                 }
 }
 
-template <int WM, int WN, int MF, int PITER>
+template <int EL, int WM, int WN, int MF, int PITER>
 static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
-    auto k = conv_mfma_kernel<WM, WN, MF, PITER>;
+    auto k = conv_mfma_kernel<EL, WM, WN, MF, PITER>;
     static size_t cur = 0;   // per-instantiation high-water mark of the opt-in dynamic LDS size
     if (smem > cur) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -905,11 +951,11 @@ static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream
     return hipGetLastError();
 }
 
-template <int WM, int WN, int MF, int PITER>
+template <int EL, int WM, int WN, int MF, int PITER>
 static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
     const size_t smem = (size_t)2 * WN * 64 * 64 + (size_t)2 * a.NP * 64;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    return launch_one<WM, WN, MF, PITER>(a, smem, grid, s);
+    return launch_one<EL, WM, WN, MF, PITER>(a, smem, grid, s);
 }
 
 static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 variant (A/B runs)
@@ -920,13 +966,17 @@ static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 v
 // BBOCR_CONV_STAMPS=<dir>: diagnostic tile timeline — every 3x3 DMA launch is followed by a sync and dumps its per-workgroup
 // s_memtime stamps to <dir>/stamps_<seq>_<Cin>x<Cout>_<H>x<W>_g<grid>.bin (tools/tile_timeline.py reads them)
 static const char* conv_stamps_dir() {
+#ifdef BBOCR_DIAG
     static const char* d = getenv("BBOCR_CONV_STAMPS");
     return d;
+#else
+    return nullptr;
+#endif
 }
 
-template <int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<WM, WN, MF, NPB, RING, NPS, FUSE1, NF>;
+    auto k = conv3x3_dma_kernel<EL, WM, WN, MF, NPB, RING, NPS, FUSE1, NF>;
     const size_t smem_max = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     // a single 32-channel chunk (conv_cls: Cin = 32) never touches the second patch buffer: without it a workgroup needs 33 KB and
     // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
@@ -963,7 +1013,7 @@ static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int WM, int WN, int MF>
+template <int EL, int WM, int WN, int MF>
 static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s) {
     const size_t wb = (size_t)WN * 64 * 64, pb = (size_t)2 * npb * 64 * 64;
     static const int ring_cap = [] { const char* e = getenv("BBOCR_DMA_RING"); return e ? atoi(e) : 4; }();
@@ -974,17 +1024,17 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
         static const bool three = [] { const char* e = getenv("BBOCR_CONV_3WG"); return !(e && e[0] == '0'); }();
         if (a.c11_w) {   // conv1_2 with the conv1_1 producer fused in
             if (!(npb == 6 && a.PH * a.PW == 324 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
-            return launch_dma_one<WM, WN, MF, 6, 3, 324, true>(a, grid, s);
+            return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, true>(a, grid, s);
         }
         if (three && npb == 6 && a.PH * a.PW == 324) {
             static const bool half = [] { const char* e = getenv("BBOCR_CONV_NF2"); return !(e && e[0] == '0'); }();   // A/B knob
-            if (half && a.cout_store <= 32) return launch_dma_one<WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
-            return launch_dma_one<WM, WN, MF, 6, 3, 324>(a, grid, s);
+            if (half && a.cout_store <= 32) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
+            return launch_dma_one<EL, WM, WN, MF, 6, 3, 324>(a, grid, s);
         }
-        if (npb == 6) return launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
+        if (npb == 6) return launch_dma_one<EL, WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
     }
-    if (npb == 6) return r4 ? launch_dma_one<WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<WM, WN, MF, 6, 3>(a, grid, s);
-    if (npb == 7) return launch_dma_one<WM, WN, MF, 7, 3>(a, grid, s);
+    if (npb == 6) return r4 ? launch_dma_one<EL, WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<EL, WM, WN, MF, 6, 3>(a, grid, s);
+    if (npb == 7) return launch_dma_one<EL, WM, WN, MF, 7, 3>(a, grid, s);
     return hipErrorInvalidValue;
 }
 
@@ -993,7 +1043,8 @@ int conv_plan_bn(int Cout) {   // couts per workgroup tile (BBOCR_BN64_UPTO: A/B
     return Cout > bn64_upto ? 128 : 64;
 }
 
-hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
+template <int EL>
+static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     const int BN = p.BN;
     constexpr int NWV = 4;       // waves per workgroup
     constexpr int BM = 256;      // output pixels per workgroup tile
@@ -1030,7 +1081,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             a.dbg = 0;
             const long long g = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
             if (g > 0 && g <= 0x7fffffffLL)
-                return BN == 128 ? launch_dma<2, 2, 8>(a, a.NP / 64, (int)g, s) : launch_dma<4, 1, 4>(a, a.NP / 64, (int)g, s);
+                return BN == 128 ? launch_dma<EL, 2, 2, 8>(a, a.NP / 64, (int)g, s) : launch_dma<EL, 4, 1, 4>(a, a.NP / 64, (int)g, s);
             a.sub = 1;
             a.stack = 0;
         }
@@ -1062,8 +1113,12 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     if ((a.in0_cs & 7) || (a.C1 && (a.in1_cs & 7)) || (a.out_cs & (a.out_f32 ? 3 : 7)) || (a.cout_store & 15)) return hipErrorInvalidValue;
     a.wpk = p.d_w;
     a.bias = p.d_b;
+#ifdef BBOCR_DIAG
     static const int dbg = [] { const char* e = getenv("BBOCR_CONV_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     const long long grid_ll = (long long)a.N * a.tiles_x * a.tiles_y * a.ntiles_n;
     if (grid_ll <= 0 || grid_ll > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = (int)grid_ll;
@@ -1071,16 +1126,22 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
                      a.cout_store == p.Cout_pad))
         return hipErrorInvalidValue;
     if (conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
-        return BN == 128 ? launch_dma1x1<2, 2, 8>(a, s) : launch_dma1x1<4, 1, 4>(a, s);
+        return BN == 128 ? launch_dma1x1<EL, 2, 2, 8>(a, s) : launch_dma1x1<EL, 4, 1, 4>(a, s);
     if (conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
         const int npb = cdiv(a.PH * a.PW, 64);
         if (npb == 6 || npb == 7) {
             a.NP = npb * 64;
-            return BN == 128 ? launch_dma<2, 2, 8>(a, npb, grid, s) : launch_dma<4, 1, 4>(a, npb, grid, s);
+            return BN == 128 ? launch_dma<EL, 2, 2, 8>(a, npb, grid, s) : launch_dma<EL, 4, 1, 4>(a, npb, grid, s);
         }
     }
     const int piter = cdiv(a.NP / 16, NWV);
-    if (BN == 128) return piter <= 4 ? launch_cfg<2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<2, 2, 8, 8>(a, grid, s) : launch_cfg<2, 2, 8, 16>(a, grid, s));
-    if (BN == 64) return piter <= 4 ? launch_cfg<4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<4, 1, 4, 8>(a, grid, s) : launch_cfg<4, 1, 4, 16>(a, grid, s));
+    if (BN == 128) return piter <= 4 ? launch_cfg<EL, 2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 2, 2, 8, 8>(a, grid, s) : launch_cfg<EL, 2, 2, 8, 16>(a, grid, s));
+    if (BN == 64) return piter <= 4 ? launch_cfg<EL, 4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 4, 1, 4, 8>(a, grid, s) : launch_cfg<EL, 4, 1, 4, 16>(a, grid, s));
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s) {
+    a.acc_scale = p.acc_scale;
+    if (a.split_off && (a.out_f32 || a.tail || a.addup || p.el != 1)) return hipErrorInvalidValue;   // hi|lo outputs: fp16 stores only
+    return p.el ? launch_conv_el<1>(p, a, s) : launch_conv_el<0>(p, a, s);
 }

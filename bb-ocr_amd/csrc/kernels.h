@@ -41,6 +41,10 @@ struct ConvArgs {
     const float* c11_b;
     int rgb_H, rgb_W;
     unsigned long long* stamps;   // diagnostic (BBOCR_CONV_STAMPS): per workgroup {t_start, t_prologue, t_mainloop, t_end} s_memtime; null in production
+    float acc_scale;       // accumulators are multiplied by this before the bias (set from ConvPlan::acc_scale by launch_conv; 1 unless
+                           // the packed weights carry a power-of-two scale, see the split-fp16 plans)
+    int split_off;         // > 0 (fp16 element type only): every stored value v goes out as the pair hi = fp16(v) at its channel and
+                           // lo = fp16(v - hi) at channel + split_off -- the [hi | lo] activation layout of the exact recogniser mode
 };
 
 struct ConvPlan {      // host-side description of one packed conv layer
@@ -48,6 +52,8 @@ struct ConvPlan {      // host-side description of one packed conv layer
     int Cin_pad = 0, Cout_pad = 0;
     int KH = 1, KW = 1, pad_h = 0, pad_w = 0, dil = 1;
     int BN = 64;       // cout tile of the launch config chosen for this layer (64/128/256)
+    int el = 0;        // element type of the packed weights and of the activations this layer reads / writes: 0 bf16, 1 fp16
+    float acc_scale = 1.f;   // 2^-s when the packed weights are w * 2^s (exact; split-fp16 plans keep w_lo out of fp16's subnormals)
     uint16_t* d_w = nullptr;   // device packed weights
     float* d_b = nullptr;      // device bias [Cout_pad]
 };
