@@ -168,7 +168,7 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
         HostBoxes hb;
         hb.polys.resize(B); hb.hori.resize(B); hb.freeb.resize(B);
         RecEarly early;
-        static const bool early_on = [] { const char* e = getenv("BBOCR_REC_EARLY"); return !(e && e[0] == '0'); }();   // A/B knob
+        static const bool early_on = (diag_knob("BBOCR_REC_EARLY", 1) != 0);   // A/B knob
         for (size_t k = 0; k < subs.size(); ++k) {
             const int b0 = subs[k].first, nb = subs[k].second;
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->sub_events[k], 0));

@@ -120,7 +120,7 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
     return guarded(ctx, [&] {
         if (!dev_in || !w || Cin <= 0 || (Cin & 31) || Cout <= 0 || KH <= 0 || KW <= 0) fail(BBOCR_ERR_ARG, "bad conv arguments");
         if (pool_mode < 0 || pool_mode > 2 || (pool_mode ? (!dev_pool_out || out_f32) : !dev_out)) fail(BBOCR_ERR_ARG, "bad conv output arguments");
-        ConvPlan p = make_plan(Cin, Cout, KH, KW, pad, dil);
+        ConvPlan p = make_plan(Cin, Cout, KH, KW, pad, dil, det_el(ctx));     // element type of the context's precision (bf16 / fp16)
         std::vector<float> wv(w, w + (size_t)Cout * Cin * KH * KW), bv(Cout, 0.f);
         if (bias) std::copy(bias, bias + Cout, bv.begin());
         const size_t owned0 = ctx->owned.size();
@@ -147,7 +147,7 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
         if (!dev_crops || !dev_logits || n <= 0 || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop batch");
         const int T = imgW / 4 - 1;
         const size_t rows = (size_t)n * T, rows_pad = align_up(rows, 256);
-        ctx->seq_v.ensure(rows_pad * 256 * 2);
+        ctx->seq_v.ensure(rows_pad * 256 * 2 * (rec_split(ctx) ? 2 : 1));
         ctx->seq_logits.ensure(rows_pad * 112 * 4);
         ctx->arena.begin(true);
         crnn_features(ctx, dev_crops, n, imgW, nullptr);
@@ -292,7 +292,7 @@ int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const 
         }
         HIPCHK(launch_crops(dev_gray, H, W, (const CropDesc*)ctx->crop_desc.p, 0, (int)descs.size(), imgW, any_warp, any_tall,
                             (uint8_t*)ctx->crop_wscratch.p, (uint8_t*)ctx->crop_scratch.p, (uint8_t*)ctx->crop_hscratch.p,
-                            (const uint8_t*)ctx->crop_luts.p, dev_out, 2, ctx->stream));
+                            (const uint8_t*)ctx->crop_luts.p, dev_out, 2, ctx->stream, 0, 0, rec_mode(ctx)));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     });
 }

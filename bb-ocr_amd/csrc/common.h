@@ -88,6 +88,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// A/B switches of the measurement campaign (BBOCR_* environment variables) exist in diagnostic builds only (make DIAG=1): the shipped
+// library always takes the measured-best default and does not read the environment.
+#ifdef BBOCR_DIAG
+#include <stdlib.h>
+static inline int diag_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int diag_knob(const char*, int dflt) { return dflt; }
+#endif
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \

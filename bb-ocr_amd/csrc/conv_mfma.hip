@@ -137,12 +137,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
             if (run1) *(u32x4*)(op + 32) = hi;
         }
     };
-    // a.split_off (exact recogniser mode, fp16): v = hi + lo with hi = fp16(v), lo = fp16(v - hi): 22 significand bits in two fp16 tensors
+    // a.split_off (exact recogniser mode, fp16): v = hi + lo / 2048 with hi = fp16(v), lo = fp16((v - hi) * 2048): 22 significand bits in
+    // two fp16 tensors, the low one scaled into fp16's normal range (its weight block carries the 2^-11, weights.cpp::upload_split_plan)
     auto split_hi_lo = [&](const float (&v)[16], float (&vh)[16], float (&vl)[16]) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             vh[i] = El<EL>::to_f32(El<EL>::from_f32(v[i]));
-            vl[i] = v[i] - vh[i];
+            vl[i] = (v[i] - vh[i]) * SPLIT_LO_SCALE;
         }
     };
     auto store_frag = [&](void* base, size_t row, int cs, int xb, int xlim, bool row_ok, const float (&v)[16], bool f32) {
@@ -959,7 +960,7 @@ static hipError_t launch_cfg(const ConvArgs& a, int grid, hipStream_t s) {
 }
 
 static bool conv_dma() {   // BBOCR_CONV_DMA=0 disables the LDS-DMA staged 3x3 variant (A/B runs)
-    static const bool v = [] { const char* e = getenv("BBOCR_CONV_DMA"); return !(e && e[0] == '0'); }();
+    static const bool v = (diag_knob("BBOCR_CONV_DMA", 1) != 0);
     return v;
 }
 
@@ -980,7 +981,7 @@ static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
     const size_t smem_max = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     // a single 32-channel chunk (conv_cls: Cin = 32) never touches the second patch buffer: without it a workgroup needs 33 KB and
     // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
-    static const bool one_buf = [] { const char* e = getenv("BBOCR_CONV_1BUF"); return !(e && e[0] == '0'); }();   // A/B knob
+    static const bool one_buf = (diag_knob("BBOCR_CONV_1BUF", 1) != 0);   // A/B knob
     const size_t smem = (one_buf && a.nchunks == 1 && !FUSE1) ? smem_max - (size_t)NPS * 64 : smem_max;
     static bool attr = false;
     if (!attr) {
@@ -1016,18 +1017,18 @@ static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
 template <int EL, int WM, int WN, int MF>
 static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s) {
     const size_t wb = (size_t)WN * 64 * 64, pb = (size_t)2 * npb * 64 * 64;
-    static const int ring_cap = [] { const char* e = getenv("BBOCR_DMA_RING"); return e ? atoi(e) : 4; }();
+    static const int ring_cap = diag_knob("BBOCR_DMA_RING", 4);
     const bool r4 = ring_cap >= 4 && 4 * wb + pb <= 80 * 1024;      // deepest ring that still lets two workgroups share a CU
     if constexpr (WN == 1) {
         // BN = 64: k-steps are short (16 MFMAs per wave), what pays is a THIRD co-resident workgroup: 16x16 tiles with the patch
         // trimmed to its 18 x 18 = 324 pixels and a 3-deep weight ring are 53,760 B of LDS (3 x 53,760 <= 160 KB)
-        static const bool three = [] { const char* e = getenv("BBOCR_CONV_3WG"); return !(e && e[0] == '0'); }();
+        static const bool three = (diag_knob("BBOCR_CONV_3WG", 1) != 0);
         if (a.c11_w) {   // conv1_2 with the conv1_1 producer fused in
             if (!(npb == 6 && a.PH * a.PW == 324 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, true>(a, grid, s);
         }
         if (three && npb == 6 && a.PH * a.PW == 324) {
-            static const bool half = [] { const char* e = getenv("BBOCR_CONV_NF2"); return !(e && e[0] == '0'); }();   // A/B knob
+            static const bool half = (diag_knob("BBOCR_CONV_NF2", 1) != 0);   // A/B knob
             if (half && a.cout_store <= 32) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324>(a, grid, s);
         }
@@ -1039,7 +1040,7 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
 }
 
 int conv_plan_bn(int Cout) {   // couts per workgroup tile (BBOCR_BN64_UPTO: A/B knob, measured no gain for the 128-cout layers)
-    static const int bn64_upto = [] { const char* e = getenv("BBOCR_BN64_UPTO"); return e ? atoi(e) : 64; }();
+    static const int bn64_upto = diag_knob("BBOCR_BN64_UPTO", 64);
     return Cout > bn64_upto ? 128 : 64;
 }
 
@@ -1114,7 +1115,7 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     a.wpk = p.d_w;
     a.bias = p.d_b;
 #ifdef BBOCR_DIAG
-    static const int dbg = [] { const char* e = getenv("BBOCR_CONV_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = diag_knob("BBOCR_CONV_DBG", 0);
     a.dbg = dbg;
 #else
     a.dbg = 0;

@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(256) crop_pil_h_kernel(const CropDesc* __restr
 // Output addressing: bucket tensor [slot][64][imgW] (row_stride = imgW, slot_stride = 64*imgW, gap = 0) or ONE wide image
 // [64][Wt] holding every crop side by side (row_stride = Wt, slot_stride = 1, slot = the crop's first column, gap zero columns
 // after it: the conv layers' zero padding between neighbours).
+template <int MODE>
 __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restrict__ descs, int first, const uint8_t* __restrict__ scratch,
                                                          const uint8_t* __restrict__ hscratch, const uint8_t* __restrict__ luts,
                                                          uint16_t* __restrict__ out, int row_stride, long long slot_stride, int gap) {
@@ -210,7 +211,8 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
             for (int k = 0; k < win.n; ++k) acc += (long long)src[(size_t)(win.x0 + k) * d.fw + xs] * pil_tap(win, k);
             v = pil_clip8(acc);
         }
-        return f32_to_bf16_bits(((float)v / 255.0f - 0.5f) / 0.5f);
+        if constexpr (MODE == REC_SPLIT) return (unsigned short)(v + 1);          // code: conv0 rebuilds the fp32 value exactly
+        else return El<MODE == REC_F16 ? 1 : 0>::from_f32(((float)v / 255.0f - 0.5f) / 0.5f);
     };
     uint16_t* drow = dst + (size_t)y * row_stride;
     for (int x = imgW + x0; x < imgW + gap; x += 64) drow[x] = 0;     // zero separator columns (wide layout)
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(256) crop_final_kernel(const CropDesc* __restr
 
 hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
                         int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
-                        int stage_mask, hipStream_t s, int wide_row_stride, int gap) {
+                        int stage_mask, hipStream_t s, int wide_row_stride, int gap, int mode) {
     if (count <= 0) return hipSuccess;
     if (stage_mask & 1) {
         if (any_warp) hipLaunchKernelGGL(crop_warp_kernel, dim3(16, count), dim3(256), 0, s, gray, H, W, descs_dev, first, wscratch);
@@ -232,12 +234,15 @@ hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs
     }
     if (stage_mask & 2) {
         if (any_tall) hipLaunchKernelGGL(crop_pil_h_kernel, dim3(8, count), dim3(256), 0, s, descs_dev, first, scratch, luts, hscratch);
-        if (wide_row_stride > 0)
-            hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket,
-                               wide_row_stride, 1LL, gap);
+        const int rs = wide_row_stride > 0 ? wide_row_stride : imgW;
+        const long long ss = wide_row_stride > 0 ? 1LL : (long long)64 * imgW;
+        const int gp = wide_row_stride > 0 ? gap : 0;
+        if (mode == REC_SPLIT)
+            hipLaunchKernelGGL(crop_final_kernel<REC_SPLIT>, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, rs, ss, gp);
+        else if (mode == REC_F16)
+            hipLaunchKernelGGL(crop_final_kernel<REC_F16>, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, rs, ss, gp);
         else
-            hipLaunchKernelGGL(crop_final_kernel, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, imgW,
-                               (long long)64 * imgW, 0);
+            hipLaunchKernelGGL(crop_final_kernel<REC_BF16>, dim3(16, count), dim3(256), 0, s, descs_dev, first, scratch, hscratch, luts, out_bucket, rs, ss, gp);
     }
     return hipGetLastError();
 }
@@ -250,6 +255,7 @@ hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, i
 
 // ------------------------------------------------------------------------------------------------ CRNN conv0 + pool
 // FeatureExtraction.ConvNet.0 (1->32, 3x3, pad 1) + ReLU + MaxPool2d(2,2): one pooled pixel x 32 channels per thread.
+template <int MODE>
 __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ b, uint16_t* __restrict__ out, int n, int W) {
     const int OW = W / 2, OH = 32;
@@ -266,12 +272,18 @@ __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restr
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
-                v[dy][dx] = (iy >= 0 && iy < 64 && ix >= 0 && ix < W) ? bf16_bits_to_f32(p[(size_t)iy * W + ix]) : 0.f;
+                float x = 0.f;
+                if (iy >= 0 && iy < 64 && ix >= 0 && ix < W) {
+                    const unsigned short q = p[(size_t)iy * W + ix];
+                    if constexpr (MODE == REC_SPLIT) x = q ? ((float)(q - 1) / 255.0f - 0.5f) / 0.5f : 0.f;      // ToTensor + sub_(0.5).div_(0.5) in fp32
+                    else x = El<MODE == REC_F16 ? 1 : 0>::to_f32(q);
+                }
+                v[dy][dx] = x;
             }
-        uint16_t* op = out + i * 32;
+        uint16_t* op = out + i * (MODE == REC_SPLIT ? 64 : 32);
 #pragma unroll 1
         for (int c8 = 0; c8 < 32; c8 += 8) {        // 8 channels -> one 16-byte store
-            u32x4 o;
+            u32x4 o, ol;
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
                 // two channels at a time on the packed fp32 pipe (v_pk_fma_f32): w is tap-major [9][32], so a channel pair of
@@ -295,45 +307,82 @@ __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restr
                             }
                         best = __builtin_elementwise_max(best, a);
                     }
-                o[c2] = pack_bf16x2(best[0], best[1]);
+                if constexpr (MODE == REC_SPLIT) {
+                    const float h0 = El<1>::to_f32(El<1>::from_f32(best[0])), h1 = El<1>::to_f32(El<1>::from_f32(best[1]));
+                    o[c2] = El<1>::pack2(h0, h1);
+                    ol[c2] = El<1>::pack2((best[0] - h0) * SPLIT_LO_SCALE, (best[1] - h1) * SPLIT_LO_SCALE);
+                } else {
+                    o[c2] = El<MODE == REC_F16 ? 1 : 0>::pack2(best[0], best[1]);
+                }
             }
             *(u32x4*)(op + c8) = o;
+            if constexpr (MODE == REC_SPLIT) *(u32x4*)(op + 32 + c8) = ol;
         }
     }
 }
 
-hipError_t launch_crnn_conv0(const uint16_t* in, const float* w, const float* b, uint16_t* out, int n, int W, hipStream_t s) {
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s) {
     const size_t total = (size_t)n * 32 * (W / 2);
     if (total == 0) return hipSuccess;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(crnn_conv0_kernel, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
+    if (mode == REC_SPLIT) hipLaunchKernelGGL(crnn_conv0_kernel<REC_SPLIT>, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
+    else if (mode == REC_F16) hipLaunchKernelGGL(crnn_conv0_kernel<REC_F16>, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
+    else hipLaunchKernelGGL(crnn_conv0_kernel<REC_BF16>, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ mean over 3 rows
+// AdaptiveAvgPool2d((None, 1)) over the 3 feature rows for 8 channels: p0 / p1 / p2 point at the 8 channels of the three rows.
+// REC_SPLIT: the rows are [hi C | lo C] pairs (lo_off elements apart), the mean is taken on hi + lo/2048 in fp32 and split again.
+template <int MODE>
+__device__ __forceinline__ void rowmean3_8(const uint16_t* p0, const uint16_t* p1, const uint16_t* p2, uint16_t* o, int lo_off) {
+    typedef El<MODE == REC_BF16 ? 0 : 1> E;
+    const u32x4 a = *(const u32x4*)(p0), bq = *(const u32x4*)(p1), c = *(const u32x4*)(p2);
+    u32x4 oh, ol;
+    if constexpr (MODE == REC_SPLIT) {
+        const u32x4 al = *(const u32x4*)(p0 + lo_off), bl = *(const u32x4*)(p1 + lo_off), cl = *(const u32x4*)(p2 + lo_off);
+        const float inv = 1.0f / SPLIT_LO_SCALE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2_t m = ((E::unpack2(a[j]) + E::unpack2(al[j]) * inv) + (E::unpack2(bq[j]) + E::unpack2(bl[j]) * inv) +
+                               (E::unpack2(c[j]) + E::unpack2(cl[j]) * inv)) / 3.0f;
+            const f32x2_t h = E::unpack2(E::pack2(m[0], m[1]));
+            oh[j] = E::pack2(h[0], h[1]);
+            ol[j] = E::pack2((m[0] - h[0]) * SPLIT_LO_SCALE, (m[1] - h[1]) * SPLIT_LO_SCALE);
+        }
+        *(u32x4*)(o) = oh;
+        *(u32x4*)(o + lo_off) = ol;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2_t m = (E::unpack2(a[j]) + E::unpack2(bq[j]) + E::unpack2(c[j])) / 3.0f;
+            oh[j] = E::pack2(m[0], m[1]);
+        }
+        *(u32x4*)(o) = oh;
+    }
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(256) rowmean3_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int T, int C8) {
+    constexpr int M = MODE == REC_SPLIT ? 2 : 1;             // stored channels per logical channel
     const size_t total = (size_t)n * T * C8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t per = (size_t)T * C8;
         const size_t img = i / per, rem = i - img * per;
-        const uint16_t* p = in + (img * 3 * per + rem) * 8;
-        const u32x4 a = *(const u32x4*)(p), bq = *(const u32x4*)(p + per * 8), c = *(const u32x4*)(p + 2 * per * 8);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = (__uint_as_float(a[j] << 16) + __uint_as_float(bq[j] << 16) + __uint_as_float(c[j] << 16)) / 3.0f;
-            const float hi = (__uint_as_float(a[j] & 0xffff0000u) + __uint_as_float(bq[j] & 0xffff0000u) + __uint_as_float(c[j] & 0xffff0000u)) / 3.0f;
-            o[j] = pack_bf16x2(lo, hi);
-        }
-        *(u32x4*)(out + i * 8) = o;
+        const size_t t = rem / C8, c8 = rem - t * C8;
+        const size_t row = (size_t)T * C8 * 8 * M;           // elements of one feature row
+        const uint16_t* p = in + img * 3 * row + (t * C8 * M + c8) * 8;
+        rowmean3_8<MODE>(p, p + row, p + 2 * row, out + ((img * T + t) * C8 * M + c8) * 8, C8 * 8);
     }
 }
 
-hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s) {
+hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, int mode, hipStream_t s) {
     const size_t total = (size_t)n * T * (C / 8);
     if (total == 0) return hipSuccess;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(rowmean3_kernel, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
+    if (mode == REC_SPLIT) hipLaunchKernelGGL(rowmean3_kernel<REC_SPLIT>, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
+    else if (mode == REC_F16) hipLaunchKernelGGL(rowmean3_kernel<REC_F16>, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
+    else hipLaunchKernelGGL(rowmean3_kernel<REC_BF16>, dim3(grid), dim3(256), 0, s, in, out, n, T, C / 8);
     return hipGetLastError();
 }
 
@@ -361,28 +410,25 @@ hipError_t launch_crnn_zero_gaps(uint16_t* t, const CropDesc* descs_dev, int fir
 
 // AdaptiveAvgPool over the 3 feature rows + gather: wide features [3][Wc][C] -> pooled rows [row0 + t][C] of every crop
 // (columns slot/4 .. slot/4 + T - 1, T = imgW/4 - 1, row0 = CropDesc::pad_)
+template <int MODE>
 __global__ void __launch_bounds__(256) rowmean3_gather_kernel(const uint16_t* __restrict__ in, int Wc, int C8, const CropDesc* __restrict__ descs,
                                                               int first, uint16_t* __restrict__ out) {
+    constexpr int M = MODE == REC_SPLIT ? 2 : 1;
     const CropDesc d = descs[first + blockIdx.y];
     const int T = d.imgW / 4 - 1, xs = d.slot >> 2;
-    const size_t plane = (size_t)Wc * C8 * 8;
+    const size_t plane = (size_t)Wc * C8 * 8 * M;
     const int total = T * C8;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int t = i / C8, c8 = i - t * C8;
-        const uint16_t* p = in + ((size_t)(xs + t) * C8 + c8) * 8;
-        const u32x4 a = *(const u32x4*)(p), bq = *(const u32x4*)(p + plane), c = *(const u32x4*)(p + 2 * plane);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = (__uint_as_float(a[j] << 16) + __uint_as_float(bq[j] << 16) + __uint_as_float(c[j] << 16)) / 3.0f;
-            const float hi = (__uint_as_float(a[j] & 0xffff0000u) + __uint_as_float(bq[j] & 0xffff0000u) + __uint_as_float(c[j] & 0xffff0000u)) / 3.0f;
-            o[j] = pack_bf16x2(lo, hi);
-        }
-        *(u32x4*)(out + ((size_t)(d.pad_ + t) * C8 + c8) * 8) = o;
+        const uint16_t* p = in + ((size_t)(xs + t) * C8 * M + c8) * 8;
+        rowmean3_8<MODE>(p, p + plane, p + 2 * plane, out + ((size_t)(d.pad_ + t) * C8 * M + c8) * 8, C8 * 8);
     }
 }
-hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, hipStream_t s) {
+hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, int mode,
+                                  hipStream_t s) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rowmean3_gather_kernel, dim3(8, count), dim3(256), 0, s, in, Wc, C / 8, descs_dev, first, out);
+    if (mode == REC_SPLIT) hipLaunchKernelGGL(rowmean3_gather_kernel<REC_SPLIT>, dim3(8, count), dim3(256), 0, s, in, Wc, C / 8, descs_dev, first, out);
+    else if (mode == REC_F16) hipLaunchKernelGGL(rowmean3_gather_kernel<REC_F16>, dim3(8, count), dim3(256), 0, s, in, Wc, C / 8, descs_dev, first, out);
+    else hipLaunchKernelGGL(rowmean3_gather_kernel<REC_BF16>, dim3(8, count), dim3(256), 0, s, in, Wc, C / 8, descs_dev, first, out);
     return hipGetLastError();
 }

@@ -135,7 +135,6 @@ struct bbocr_ctx {
 
     // ---- detector
     bool craft_loaded = false;
-    uint16_t* c11_w = nullptr;
     uint16_t* c11_wf = nullptr;               // conv1_1 weights in the layout of the producer fused into conv1_2
     float* c11_b = nullptr;
     ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
@@ -150,6 +149,7 @@ struct bbocr_ctx {
     float* r0_wb = nullptr;      // w[9][32] (tap-major) b[32]
     ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
     uint16_t* whh[2] = {nullptr, nullptr};
+    float whh_scale[2] = {1.f, 1.f};   // exact mode: 2^-s of the packed W_hh (pack_lstm_whh_split)
     std::vector<void*> owned;    // every hipMalloc'd weight block
 
     void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
@@ -162,6 +162,11 @@ struct bbocr_ctx {
     PinBuf ctc_pin;                           // CTC results land here (pinned: the 1.7 MB D2H copy of a 64-page pass runs at link speed)
     DevBuf seq_v, seq_xp, seq_h, seq_lin, seq_logits, seq_tables;
 };
+
+// element type of a network's MFMA operands / stored activations (El<> in common.h), from bbocr_config::precision
+inline int det_el(const bbocr_ctx* c) { return c->cfg.precision >= BBOCR_PREC_FP16 ? 1 : 0; }
+inline int rec_el(const bbocr_ctx* c) { return c->cfg.precision >= BBOCR_PREC_FP16 ? 1 : 0; }
+inline bool rec_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT; }   // recogniser tensors are [hi | lo] fp16 pairs
 
 // ------------------------------------------------------------------------------------------------ shared types
 struct TensorMap {
@@ -248,7 +253,7 @@ template <typename T> inline T* upload(bbocr_ctx* c, const std::vector<T>& v) {
     return (T*)d;
 }
 
-ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil);
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el = 0);
 void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b);
 void free_weights(bbocr_ctx* c);
 void load_craft(bbocr_ctx* c, const TensorMap& tm);
@@ -266,6 +271,7 @@ bbocr_boxlist* export_boxes(const HostBoxes& hb);
 void import_boxes(const bbocr_boxlist* bl, HostBoxes& hb);
 bool plan_horizontal(const std::array<int, 4>& box, int img, int H, int W, BoxJob& j);
 bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j);
+int rec_mode(const bbocr_ctx* c);
 void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_t* v_out);
 void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, int ntiles, float* logits);
 double percentile_u8(const unsigned int* hist, size_t n, double q);

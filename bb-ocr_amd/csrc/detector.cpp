@@ -28,16 +28,28 @@ void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
     c->prof_recs.push_back(r);
 }
 
+// Split-fp16 plans (ConvPlan::split, exact recogniser mode): the activation `a0` is a pair tensor [hi | lo] whose Act::C counts BOTH
+// halves; the launch reads [hi | lo | hi] (in1 = the hi half again) and, unless it writes fp32, stores its output as a pair too.
+static void conv_sources(const ConvPlan& p, ConvArgs& a, const Act& a0, const Act* a1) {
+    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
+    if (p.split) {
+        if (a1 || (a0.C & 63)) fail(BBOCR_ERR_INTERNAL, "split-fp16 conv: one pair tensor with a multiple of 32 logical channels expected");
+        a.in1 = a0.p; a.C1 = a0.C / 2; a.in1_cs = a0.C;
+    } else if (a1) {
+        a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C;
+    }
+}
+
 void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out,
                      int out_cs, int cout_store, bool out_f32, const Act* addup) {
     if (c->arena.dry) return;
     ConvArgs a{};
     if (addup) { a.addup = addup->p; a.up_H = a0.H; a.up_W = a0.W; a.up_cs = addup->C; }
-    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
-    if (a1) { a.in1 = a1->p; a.C1 = a1->C; a.in1_cs = a1->C; }
+    conv_sources(p, a, a0, a1);
     a.N = a0.N; a.H = a0.H; a.W = a0.W;
-    a.relu_in0 = relu0; a.relu_in1 = relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
+    a.relu_in0 = relu0; a.relu_in1 = p.split ? relu0 : relu1; a.relu_out = relu_out; a.out_f32 = out_f32;
     a.out = out; a.out_cs = out_cs; a.cout_store = cout_store;
+    if (p.split && !out_f32) a.split_off = cout_store;          // out_cs is 2 * cout_store then
     launch_conv_profiled(c, p, a);
 }
 
@@ -59,8 +71,9 @@ void prof_collect(bbocr_ctx* c) {
 // conv producing a fresh bf16 activation with `store` channels (multiple of 16)
 Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, int store) {
     const int OH = a0.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a0.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
-    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * store), a0.N, OH, OW, store};
-    run_conv(c, p, a0, relu0, a1, relu1, relu_out, o.p, store, store, false);
+    const int cs = p.split ? 2 * store : store;                  // pair tensors carry [hi | lo]
+    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * cs), a0.N, OH, OW, cs};
+    run_conv(c, p, a0, relu0, a1, relu1, relu_out, o.p, cs, store, false);
     return o;
 }
 
@@ -70,15 +83,18 @@ Act conv_pool_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, bo
                          Act* full, const RgbSource* rgb) {
     const int OH = a0.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a0.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
     const int PH = OH / 2, PW = mode == 1 ? OW / 2 : OW;
-    if (full) *full = Act{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * store), a0.N, OH, OW, store};
-    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * PH * PW * store), a0.N, PH, PW, store};
+    const int cs = p.split ? 2 * store : store;
+    if (full) *full = Act{c->arena.alloc<uint16_t>((size_t)a0.N * OH * OW * cs), a0.N, OH, OW, cs};
+    Act o{c->arena.alloc<uint16_t>((size_t)a0.N * PH * PW * cs), a0.N, PH, PW, cs};
     if (c->arena.dry) return o;
     ConvArgs a{};
-    a.in0 = a0.p; a.C0 = a0.C; a.in0_cs = a0.C;
+    if (!rgb) conv_sources(p, a, a0, nullptr);
+    else { a.C0 = a0.C; a.in0_cs = a0.C; }
     a.N = a0.N; a.H = a0.H; a.W = a0.W;
-    a.relu_in0 = relu0; a.relu_out = relu_out; a.out_f32 = 0;
-    a.out = full ? (void*)full->p : nullptr; a.out_cs = store; a.cout_store = store;
-    a.pool_mode = mode; a.pool_relu = pool_relu; a.store_full = full != nullptr; a.pool_cs = store; a.pool_out = o.p;
+    a.relu_in0 = relu0; a.relu_in1 = relu0; a.relu_out = relu_out; a.out_f32 = 0;
+    a.out = full ? (void*)full->p : nullptr; a.out_cs = cs; a.cout_store = store;
+    if (p.split) a.split_off = store;
+    a.pool_mode = mode; a.pool_relu = pool_relu; a.store_full = full != nullptr; a.pool_cs = cs; a.pool_out = o.p;
     if (rgb) { a.in0 = (const uint16_t*)rgb->rgb; a.c11_w = c->c11_wf; a.c11_b = c->c11_b; a.rgb_H = rgb->Himg; a.rgb_W = rgb->Wimg; }
     launch_conv_profiled(c, p, a);
     return o;
@@ -96,19 +112,10 @@ Act pool_act(bbocr_ctx* c, const Act& a, int kh, int kw, int sh, int sw, int ph,
 static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
     Arena& ar = c->arena;
     c->prof_group = 0;
-    // normalise + conv1_1 + ReLU are produced inside conv1_2's prologue (its 64-channel input never reaches HBM);
-    // BBOCR_FUSE1=0 runs conv1_1 as its own kernel (A/B runs)
-    static const bool fuse1 = [] { const char* e = getenv("BBOCR_FUSE1"); return !(e && e[0] == '0'); }();
-    Act p1;
-    if (fuse1) {
-        const Act canvas{nullptr, nb, H32, W32, 64};
-        const RgbSource src{rgb, Himg, Wimg};
-        p1 = conv_pool_act(c, c->conv1_2, canvas, false, true, 64, 1, false, nullptr, &src);
-    } else {
-        Act a1{ar.alloc<uint16_t>((size_t)nb * H32 * W32 * 64), nb, H32, W32, 64};
-        if (!ar.dry) HIPCHK(launch_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w, c->c11_b, a1.p, c->cur));
-        p1 = conv_pool_act(c, c->conv1_2, a1, false, true, 64, 1, false, nullptr);          // conv1_2+BN+ReLU+pool fused
-    }
+    // normalise + conv1_1 + ReLU are produced inside conv1_2's prologue (its 64-channel input never reaches HBM)
+    const Act canvas{nullptr, nb, H32, W32, 64};
+    const RgbSource src{rgb, Himg, Wimg};
+    Act p1 = conv_pool_act(c, c->conv1_2, canvas, false, true, 64, 1, false, nullptr, &src);
     Act a3 = conv_act(c, c->conv2_1, p1, false, nullptr, false, true, 128);
     Act s1;                                                                        // slice1 ends on BatchNorm (skip tensor),
     Act p2 = conv_pool_act(c, c->conv2_2, a3, false, false, 128, 1, true, &s1);   // slice2 opens with ReLU + pool: both fused
@@ -183,7 +190,7 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
         craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
         const size_t per_page = std::max<size_t>(c->arena.off, 1);
         const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)96 << 30) / per_page));
-        static const int tail_pages = [] { const char* e = getenv("BBOCR_DET_TAIL"); return e ? atoi(e) : 8; }();   // A/B knob
+        static const int tail_pages = diag_knob("BBOCR_DET_TAIL", 8);   // A/B knob
         const int tail = (after_sub && B >= 24 && cap > tail_pages && tail_pages > 0) ? tail_pages : 0;
         const int body = B - tail, nbig = cdiv(body, cap);
         for (int i = 0; i < nbig; ++i) passes.push_back(body / nbig + (i < body % nbig ? 1 : 0));

@@ -54,6 +54,7 @@ struct ConvPlan {      // host-side description of one packed conv layer
     int BN = 64;       // cout tile of the launch config chosen for this layer (64/128/256)
     int el = 0;        // element type of the packed weights and of the activations this layer reads / writes: 0 bf16, 1 fp16
     float acc_scale = 1.f;   // 2^-s when the packed weights are w * 2^s (exact; split-fp16 plans keep w_lo out of fp16's subnormals)
+    int split = 0;     // 1: split-fp16 plan (weights.cpp::upload_split_plan): Cin counts the three blocks [a_hi | a_lo | a_hi]
     uint16_t* d_w = nullptr;   // device packed weights
     float* d_b = nullptr;      // device bias [Cout_pad]
 };
@@ -65,10 +66,7 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out);
 hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zero must be set (device zero page)
 
 // ------------------------------------------------------------------ detector front/back (craft_misc.hip)
-hipError_t launch_conv1_1(const uint8_t* rgb, int N, int Himg, int Wimg, int H32, int W32, const uint16_t* wpk, const float* bias,
-                          uint16_t* out, hipStream_t s);
-void pack_conv1_1_weights(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/);
-void pack_conv1_1_weights_fused(const float* w, uint16_t* out);   // same K order, couts in the conv epilogue's run order
+void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/, int el);   // K = tap*4 + channel, couts in the conv epilogue's run order
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
@@ -101,19 +99,31 @@ struct CropDesc {      // one recogniser input, filled on the host
 // stage_mask bit0: gather (warp) + cv2 resize into scratch; bit1: (PIL bicubic) + LUT + normalise + pad into out_bucket
 hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs_dev, int first, int count, int imgW, int any_warp,
                         int any_tall, uint8_t* wscratch, uint8_t* scratch, uint8_t* hscratch, const uint8_t* luts, uint16_t* out_bucket,
-                        int stage_mask, hipStream_t s, int wide_row_stride = 0, int gap = 0);   // wide_row_stride > 0: ONE image [64][Wt], slot = first column
+                        int stage_mask, hipStream_t s, int wide_row_stride = 0, int gap = 0, int mode = 0);   // wide_row_stride > 0: ONE image [64][Wt], slot = first column
+// Recogniser tensor modes (bbocr_config::precision): REC_BF16 / REC_F16 = 16-bit elements; REC_SPLIT = the exact mode: the crop image
+// holds CODES (0 = padding zero, 1 + grey level otherwise -- conv0 rebuilds the fp32 input ((g/255 - 0.5)/0.5) exactly), every later
+// activation is a pair of fp16 tensors [hi C | lo C] per pixel with value = hi + lo / 2048 (lo scaled so that it stays in fp16's
+// normal range), the LSTM reads an fp32 input projection.
+enum { REC_BF16 = 0, REC_F16 = 1, REC_SPLIT = 2 };
+constexpr float SPLIT_LO_SCALE = 2048.f;
 hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, int first, int count, unsigned int* hist, hipStream_t s);
-hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, hipStream_t s);
-hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, hipStream_t s);
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s);
+hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, int mode, hipStream_t s);   // C: logical channels
 // wide recogniser image (all crops side by side, CropDesc::slot = first column, ::pad_ = first pooled row): clear the separator
 // columns of a layer output [H][Wl][C] (shift = log2 horizontal down-scale), and the 3-row mean gathered into the pooled rows
 hipError_t launch_crnn_zero_gaps(uint16_t* t, const CropDesc* descs_dev, int first, int count, int H, int Wl, int C, int shift, hipStream_t s);
-hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, hipStream_t s);
+hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropDesc* descs_dev, int first, int count, uint16_t* out, int mode,
+                                  hipStream_t s);
 // BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm8_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
 // tiles_dev: int4 per workgroup {first row, sequences (<=16), T, 0}; tensors are pooled over all buckets: [rows, C]
-hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s);
+// mode REC_SPLIT: xproj is FP32 [rows, 2048], out is the pair [rows, 512 hi | 512 lo], whh_pk comes from pack_lstm_whh_split and
+// acc_scale is the inverse of its power-of-two weight scale
+hipError_t launch_lstm(const void* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, int mode, float acc_scale,
+                       hipStream_t s);
 size_t lstm_whh_packed_elems();
-void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out);
+void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out, int el);
+size_t lstm_whh_split_packed_elems();
+float pack_lstm_whh_split(const float* whh_fwd, const float* whh_bwd, uint16_t* out);   // -> acc_scale (2^-s)
 int lstm8_xproj_channel(int dir, int gate, int unit);
 struct CtcOut { int len; int cnt; float prod; int pad; };
 // seqs_dev: int2 per sequence {first row, T}; logits fp32 [rows, cs]; out_idx is row-indexed like the pool

@@ -16,6 +16,7 @@
 #include <utility>
 
 size_t lstm_whh_packed_elems() { return (size_t)2 * 1024 * 256; }
+__device__ __forceinline__ constexpr size_t lstm_whh_packed_elems_dev() { return (size_t)2 * 1024 * 256; }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): 2 transcendental issues per non-linearity instead of an IEEE division sequence
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.442695041f)); }
@@ -41,7 +42,7 @@ __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_
 #define LSTM8_S1 8      // streamed fragments fetched while the first ones are consumed
 #define LSTM8_NL 18
 #define LSTM8_LD 8      // LDS read-ahead (fragments); the ring reuses the registers of the (by then consumed) streamed buffer
-void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
+void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out, int el) {
     size_t o = 0;
     for (int d = 0; d < 2; ++d) {
         const float* W = d ? whh_bwd : whh_fwd;
@@ -52,7 +53,7 @@ void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
                         for (int l = 0; l < 64; ++l) {
                             const int unit = w * 32 + a * 16 + (l & 15);
                             const int row = gate * 256 + unit;
-                            for (int j = 0; j < 8; ++j) out[o++] = f32_to_bf16_host(W[(size_t)row * 256 + kk * 32 + 8 * (l >> 4) + j]);
+                            for (int j = 0; j < 8; ++j) out[o++] = f32_to_el_host(el, W[(size_t)row * 256 + kk * 32 + 8 * (l >> 4) + j]);
                         }
     }
 }
@@ -60,6 +61,7 @@ int lstm8_xproj_channel(int dir, int gate, int unit) {
     return dir * 1024 + (((unit >> 5) * 16 + (unit & 15)) * 8) + ((unit >> 4) & 1) * 4 + gate;
 }
 
+template <int EL>
 __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restrict__ xproj, const uint16_t* __restrict__ whh,
                                                        uint16_t* __restrict__ out, const int4* __restrict__ tiles, int pf_dist) {
     static_assert(LSTM8_S0 + LSTM8_NR + LSTM8_S1 + LSTM8_NL == 64 && LSTM8_S1 <= LSTM8_S0, "fragment classes");
@@ -79,12 +81,12 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
-    typedef const __attribute__((address_space(1))) bf16x8* gfrag_ptr;     // global_load (vmcnt only), never flat_load
-    const gfrag_ptr wv0 = (gfrag_ptr)((const bf16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane);
-    bf16x8 wreg[LSTM8_NR];
+    typedef const __attribute__((address_space(1))) typename El<EL>::v8* gfrag_ptr;     // global_load (vmcnt only), never flat_load
+    const gfrag_ptr wv0 = (gfrag_ptr)((const typename El<EL>::v8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane);
+    typename El<EL>::v8 wreg[LSTM8_NR];
 #pragma unroll
     for (int i = 0; i < LSTM8_NR; ++i) wreg[i] = wv0[(size_t)(R0 + i) * 64];
-    bf16x8* const wl = (bf16x8*)(wlds + (size_t)wave * LSTM8_NL * 1024) + lane;
+    typename El<EL>::v8* const wl = (typename El<EL>::v8*)(wlds + (size_t)wave * LSTM8_NL * 1024) + lane;
 #pragma unroll 2
     for (int i = 0; i < LSTM8_NL; ++i) wl[(size_t)i * 64] = wv0[(size_t)(L0 + i) * 64];
     const int xch = dir * 1024 + (wave * 16 + u) * 8;
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     // so that the real load finds them in L2.  The value is only kept alive until the end of the step (so that hipcc accounts for it).
     const bool pf_on = tid < 256 && pf_dist > 0;
     const size_t pf_row = ((size_t)row0 + (size_t)((tid >> 4) < n ? (tid >> 4) : n - 1) * T) * 2048 + dir * 1024 + (tid & 15) * 64;
-    bf16x8 sb[LSTM8_S0];
+    typename El<EL>::v8 sb[LSTM8_S0];
     auto stream_head = [&]() {        // fragments v = 0 .. S0-1 of the NEXT step
         gfrag_ptr wv = wv0;
         asm volatile("" : "+v"(wv));  // keep these loads inside the time loop (they would otherwise be hoisted and spilled)
@@ -122,18 +124,18 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 af[2], lb[LSTM8_LD];
-        af[0] = *(const bf16x8*)(hb);
+        typename El<EL>::v8 af[2], lb[LSTM8_LD];
+        af[0] = *(const typename El<EL>::v8*)(hb);
         auto visit = [&](auto v_c) {
             constexpr int v = decltype(v_c)::value;
             constexpr int kk = v >> 3, a = (v >> 2) & 1, q = v & 3;
-            if constexpr ((v & 7) == 0 && kk + 1 < 8) af[(kk + 1) & 1] = *(const bf16x8*)(hb + (kk + 1) * 4 * 256);   // h slice kk+1, one slice ahead
-            bf16x8 w;
+            if constexpr ((v & 7) == 0 && kk + 1 < 8) af[(kk + 1) & 1] = *(const typename El<EL>::v8*)(hb + (kk + 1) * 4 * 256);   // h slice kk+1, one slice ahead
+            typename El<EL>::v8 w;
             if constexpr (v < R0) w = sb[v];
             else if constexpr (v < S1) w = wreg[v - R0];
             else if constexpr (v < L0) w = sb[v - S1];
             else w = lb[(v - L0) % LSTM8_LD];
-            acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk & 1], w, acc[a][q], 0, 0, 0);
+            acc[a][q] = El<EL>::mfma(af[kk & 1], w, acc[a][q]);
             if constexpr (v < LSTM8_S1) sb[v] = wv[(size_t)(S1 + v) * 64];      // the buffer slot is free again: late fragment v
             // LDS read-ahead: fragment v+LD goes into the ring slot fragment v just left (the first LD reads fill the empty ring)
             if constexpr (v + LSTM8_LD >= L0 && v + LSTM8_LD < 64) lb[(v + LSTM8_LD - L0) % LSTM8_LD] = wl[(size_t)(v + LSTM8_LD - L0) * 64];
@@ -158,20 +160,19 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
 #pragma unroll
             for (int rp = 0; rp < 4; rp += 2) {
                 const unsigned int a0 = xq[rp][a * 2], a1 = xq[rp][a * 2 + 1], b0 = xq[rp + 1][a * 2], b1 = xq[rp + 1][a * 2 + 1];
-                const f32x2_t gi = (f32x2_t){acc[a][0][rp], acc[a][0][rp + 1]} + (f32x2_t){__uint_as_float(a0 << 16), __uint_as_float(b0 << 16)};
-                const f32x2_t gf = (f32x2_t){acc[a][1][rp], acc[a][1][rp + 1]} +
-                                   (f32x2_t){__uint_as_float(a0 & 0xffff0000u), __uint_as_float(b0 & 0xffff0000u)};
-                const f32x2_t gg = (f32x2_t){acc[a][2][rp], acc[a][2][rp + 1]} + (f32x2_t){__uint_as_float(a1 << 16), __uint_as_float(b1 << 16)};
-                const f32x2_t go = (f32x2_t){acc[a][3][rp], acc[a][3][rp + 1]} +
-                                   (f32x2_t){__uint_as_float(a1 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+                const f32x2_t xa0 = El<EL>::unpack2(a0), xa1 = El<EL>::unpack2(a1), xb0 = El<EL>::unpack2(b0), xb1 = El<EL>::unpack2(b1);   // (i, f), (g, o)
+                const f32x2_t gi = (f32x2_t){acc[a][0][rp], acc[a][0][rp + 1]} + (f32x2_t){xa0[0], xb0[0]};
+                const f32x2_t gf = (f32x2_t){acc[a][1][rp], acc[a][1][rp + 1]} + (f32x2_t){xa0[1], xb0[1]};
+                const f32x2_t gg = (f32x2_t){acc[a][2][rp], acc[a][2][rp + 1]} + (f32x2_t){xa1[0], xb1[0]};
+                const f32x2_t go = (f32x2_t){acc[a][3][rp], acc[a][3][rp + 1]} + (f32x2_t){xa1[1], xb1[1]};
                 const f32x2_t cp = {c[a][rp], c[a][rp + 1]};
                 const f32x2_t cn = sig2(gf) * cp + sig2(gi) * tanh2(gg);
                 c[a][rp] = cn[0];
                 c[a][rp + 1] = cn[1];
                 const f32x2_t hv = sig2(go) * tanh2(cn);
                 unsigned char* hp = hn + ((unit >> 3) * 16 + g * 4 + rp) * 16 + (unit & 7) * 2;
-                *(unsigned short*)(hp) = f32_to_bf16_bits(hv[0]);
-                *(unsigned short*)(hp + 16) = f32_to_bf16_bits(hv[1]);
+                *(unsigned short*)(hp) = El<EL>::from_f32(hv[0]);
+                *(unsigned short*)(hp + 16) = El<EL>::from_f32(hv[1]);
             }
         };
         gate_group(std::integral_constant<int, 0>{});
@@ -186,16 +187,153 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
     }
 }
 
-hipError_t launch_lstm(const uint16_t* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, hipStream_t s) {
-    if (ntiles <= 0) return hipSuccess;
-    const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
-    static bool attr8 = false;
-    if (!attr8) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
-        if (e != hipSuccess) return e;
-        attr8 = true;
+// ================================================================================================ exact mode (REC_SPLIT)
+// The same recurrence with every operand at fp32-grade precision: h (kept in fp32 registers) crosses LDS as the fp16 pair
+// hi = fp16(h), lo = fp16((h - hi) * 2048); W_hh is the pair (w_hi, w_lo) of fp16 fragments of w * 2^s; per fragment the three MFMAs
+// h_hi w_hi + h_hi w_lo (accumulator A) and h_lo w_hi (accumulator B) give  pre = (A + B / 2048) * 2^-s + x  with x the FP32 input
+// projection; gates with expf / tanhf and IEEE division, c and h in fp32; h leaves as the [hi | lo] pair the next split-fp16 GEMM
+// reads.  Same workgroup shape and fragment layout as lstm8_kernel (16 sequences x one direction, 8 waves, wave w owns units
+// [32w, 32w + 32) x 4 gates); all 128 weight fragments of a wave are re-streamed from L2 every step through a short register ring.
+size_t lstm_whh_split_packed_elems() { return 2 * lstm_whh_packed_elems(); }     // [hi image | lo image], each in pack_lstm_whh8's layout
+float pack_lstm_whh_split(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)1024 * 256; ++i) { mx = fmaxf(mx, fabsf(whh_fwd[i])); mx = fmaxf(mx, fabsf(whh_bwd[i])); }
+    int s = 0;
+    if (mx > 0.f) s = 9 - (int)floor(log2((double)mx));          // 2^9 <= mx 2^s < 2^10
+    s = s < -14 ? -14 : (s > 24 ? 24 : s);
+    const float sc = ldexpf(1.f, s);
+    const size_t half = lstm_whh_packed_elems();
+    size_t o = 0;
+    for (int d = 0; d < 2; ++d) {
+        const float* W = d ? whh_bwd : whh_fwd;
+        for (int w = 0; w < 8; ++w)
+            for (int kk = 0; kk < 8; ++kk)
+                for (int a = 0; a < 2; ++a)
+                    for (int gate = 0; gate < 4; ++gate)
+                        for (int l = 0; l < 64; ++l) {
+                            const int unit = w * 32 + a * 16 + (l & 15);
+                            const int row = gate * 256 + unit;
+                            for (int j = 0; j < 8; ++j, ++o) {
+                                const float v = W[(size_t)row * 256 + kk * 32 + 8 * (l >> 4) + j] * sc;
+                                const uint16_t hi = f32_to_f16_host(v);
+                                out[o] = hi;
+                                out[half + o] = f32_to_f16_host(v - f16_to_f32_host(hi));
+                            }
+                        }
     }
-    static const int pf_dist = [] { const char* e = getenv("BBOCR_LSTM_PF"); return e ? atoi(e) : 2; }();   // x prefetch distance in steps (0 = off)
-    hipLaunchKernelGGL(lstm8_kernel, dim3(ntiles, 2), dim3(512), smem8, s, xproj, whh_pk, out, (const int4*)tiles_dev, pf_dist);
-    return hipGetLastError();
+    return ldexpf(1.f, -s);
+}
+
+#define LSTMX_RING 6      // weight fragments (hi + lo) in flight ahead of the MFMA stream
+__global__ void __launch_bounds__(512, 1) lstm_exact_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ whh, uint16_t* __restrict__ out,
+                                                            const int4* __restrict__ tiles, float acc_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][2][32 * 16 * 16];   // [parity][hi / lo][kgroup 32][seq 16] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int4 tile = tiles[blockIdx.x];
+    const int row0 = tile.x, n = tile.y, T = tile.z;
+    const int g = lane >> 4, u = lane & 15;
+    for (int i = tid; i < (int)sizeof(hbuf) / 16; i += 512) ((u32x4*)&hbuf[0][0][0])[i] = (u32x4){0u, 0u, 0u, 0u};
+    float c[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
+    typedef const __attribute__((address_space(1))) f16x8* gfrag_ptr;
+    const size_t half_frags = lstm_whh_packed_elems_dev() / 8;
+    const gfrag_ptr whi = (gfrag_ptr)((const f16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane);
+    const gfrag_ptr wlo = whi + half_frags;
+    const int xch = dir * 1024 + (wave * 16 + u) * 8;
+    size_t xrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xrow[r] = ((size_t)row0 + (size_t)(g * 4 + r < n ? g * 4 + r : n - 1) * T) * 2048 + xch;
+    const int wb_seq = tid >> 5, wb_kg = tid & 31;   // h write-back: 16 B of hi and 16 B of lo per thread
+    const float inv_lo = 1.0f / SPLIT_LO_SCALE;
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        f32x4 xq[4][2];       // [sequence r][group a]: pre-activations (i, f, g, o) of the lane's unit
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* xp = xproj + xrow[r] + (size_t)t * 2048;
+            xq[r][0] = *(const f32x4*)(xp);
+            xq[r][1] = *(const f32x4*)(xp + 4);
+        }
+        const unsigned char* hh = hbuf[cur][0] + (g * 16 + u) * 16;
+        const unsigned char* hl = hbuf[cur][1] + (g * 16 + u) * 16;
+        f32x4 accA[2][4], accB[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { accA[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        gfrag_ptr ph = whi, pl = wlo;
+        asm volatile("" : "+v"(ph), "+v"(pl));          // keep the weight loads inside the time loop
+        f16x8 rh[LSTMX_RING], rl[LSTMX_RING];
+#pragma unroll
+        for (int i = 0; i < LSTMX_RING; ++i) { rh[i] = ph[(size_t)i * 64]; rl[i] = pl[(size_t)i * 64]; }
+        f16x8 ah, al;
+#pragma unroll
+        for (int v = 0; v < 64; ++v) {
+            const int kk = v >> 3, a = (v >> 2) & 1, q = v & 3;
+            if ((v & 7) == 0) { ah = *(const f16x8*)(hh + kk * 4 * 256); al = *(const f16x8*)(hl + kk * 4 * 256); }
+            const f16x8 wh = rh[v % LSTMX_RING], wl = rl[v % LSTMX_RING];
+            if (v + LSTMX_RING < 64) { rh[v % LSTMX_RING] = ph[(size_t)(v + LSTMX_RING) * 64]; rl[v % LSTMX_RING] = pl[(size_t)(v + LSTMX_RING) * 64]; }
+            accA[a][q] = El<1>::mfma(ah, wh, accA[a][q]);
+            accA[a][q] = El<1>::mfma(ah, wl, accA[a][q]);
+            accB[a][q] = El<1>::mfma(al, wh, accB[a][q]);
+        }
+        unsigned char* hnh = hbuf[cur ^ 1][0];
+        unsigned char* hnl = hbuf[cur ^ 1][1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int unit = wave * 32 + a * 16 + u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                auto pre = [&](int q) { return fmaf(fmaf(accB[a][q][r], inv_lo, accA[a][q][r]), acc_scale, xq[r][a][q]); };
+                const float gi = 1.0f / (1.0f + expf(-pre(0)));
+                const float gf = 1.0f / (1.0f + expf(-pre(1)));
+                const float gg = tanhf(pre(2));
+                const float go = 1.0f / (1.0f + expf(-pre(3)));
+                const float cn = gf * c[a][r] + gi * gg;
+                c[a][r] = cn;
+                const float hv = go * tanhf(cn);
+                const unsigned short hi = El<1>::from_f32(hv);
+                const unsigned short lo = El<1>::from_f32((hv - El<1>::to_f32(hi)) * SPLIT_LO_SCALE);
+                const int off = ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2;
+                *(unsigned short*)(hnh + off) = hi;
+                *(unsigned short*)(hnl + off) = lo;
+            }
+        }
+        __syncthreads();
+        if (wb_seq < n) {
+            const size_t orow = ((size_t)row0 + (size_t)wb_seq * T + t) * 1024 + dir * 256 + wb_kg * 8;
+            *(u32x4*)(out + orow) = *(const u32x4*)(hnh + (wb_kg * 16 + wb_seq) * 16);
+            *(u32x4*)(out + orow + 512) = *(const u32x4*)(hnl + (wb_kg * 16 + wb_seq) * 16);
+        }
+        cur ^= 1;
+    }
+}
+
+hipError_t launch_lstm(const void* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, int mode, float acc_scale,
+                       hipStream_t s) {
+    if (ntiles <= 0) return hipSuccess;
+    if (mode == REC_SPLIT) {
+        hipLaunchKernelGGL(lstm_exact_kernel, dim3(ntiles, 2), dim3(512), 0, s, (const float*)xproj, whh_pk, out, (const int4*)tiles_dev, acc_scale);
+        return hipGetLastError();
+    }
+    const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
+    static const int pf_dist = diag_knob("BBOCR_LSTM_PF", 2);   // x prefetch distance in steps (0 = off)
+    auto go = [&](auto kern, bool& attr) -> hipError_t {
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(ntiles, 2), dim3(512), smem8, s, (const uint16_t*)xproj, whh_pk, out, (const int4*)tiles_dev, pf_dist);
+        return hipGetLastError();
+    };
+    static bool attr_bf = false, attr_f16 = false;
+    return mode == REC_F16 ? go(lstm8_kernel<1>, attr_f16) : go(lstm8_kernel<0>, attr_bf);
 }

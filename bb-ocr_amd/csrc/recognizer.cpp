@@ -61,20 +61,25 @@ bool plan_free(const std::array<double, 8>& fq, int img, BoxJob& j) {
     return d.rw > 0 && d.rh > 0 && d.fw > 0;
 }
 
-// conv stack of the recogniser for n normalised crops of one padded width: bf16 [n,64,imgW] -> v bf16 [n*T, 256]
+// tensor mode of the recogniser (kernels.h REC_*) and stored 16-bit elements per logical channel
+int rec_mode(const bbocr_ctx* c) { return rec_split(c) ? REC_SPLIT : (rec_el(c) ? REC_F16 : REC_BF16); }
+static inline int rec_mul(const bbocr_ctx* c) { return rec_split(c) ? 2 : 1; }
+
+// conv stack of the recogniser for n normalised crops of one padded width: 16-bit [n,64,imgW] -> v [n*T, 256] (x rec_mul)
 void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_t* v_out) {
     Arena& ar = c->arena;
     c->prof_group = 1;
     const int T = imgW / 4 - 1;
-    Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32), n, 32, imgW / 2, 32};
-    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, c->cur));
+    const int m = rec_mul(c);
+    Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32 * m), n, 32, imgW / 2, 32 * m};
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, rec_mode(c), c->cur));
     Act q1 = conv_pool_act(c, c->r1, c0, false, true, 64, 1, false, nullptr);
     Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
     Act q2 = conv_pool_act(c, c->r3, c2, false, true, 128, 2, false, nullptr);
     Act c4 = conv_act(c, c->r4, q2, false, nullptr, false, true, 256);
     Act q3 = conv_pool_act(c, c->r5, c4, false, true, 256, 2, false, nullptr);
     Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [n,3,T,256]
-    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, c->cur));
+    if (!ar.dry) HIPCHK(launch_rowmean3(c6.p, v_out, n, T, 256, rec_mode(c), c->cur));
 }
 
 // The same conv stack over the WIDE image of a recognition pass: every crop side by side with 4 zero columns between
@@ -84,8 +89,9 @@ void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_
 static void crnn_features_wide(bbocr_ctx* c, const uint16_t* wide, int Wt, const CropDesc* descs, int first, int count, uint16_t* seq_v) {
     Arena& ar = c->arena;
     c->prof_group = 1;
-    Act c0{ar.alloc<uint16_t>((size_t)32 * (Wt / 2) * 32), 1, 32, Wt / 2, 32};
-    if (!ar.dry) HIPCHK(launch_crnn_conv0(wide, c->r0_wb, c->r0_wb + 288, c0.p, 1, Wt, c->cur));
+    const int m = rec_mul(c);
+    Act c0{ar.alloc<uint16_t>((size_t)32 * (Wt / 2) * 32 * m), 1, 32, Wt / 2, 32 * m};
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(wide, c->r0_wb, c->r0_wb + 288, c0.p, 1, Wt, rec_mode(c), c->cur));
     auto gaps = [&](const Act& a, int shift) {
         if (!ar.dry) HIPCHK(launch_crnn_zero_gaps(a.p, descs, first, count, a.H, a.W, a.C, shift, c->cur));
     };
@@ -101,7 +107,7 @@ static void crnn_features_wide(bbocr_ctx* c, const uint16_t* wide, int Wt, const
     Act q3 = conv_pool_act(c, c->r5, c4, false, true, 256, 2, false, nullptr);
     gaps(q3, 2);
     Act c6 = conv_act(c, c->r6, q3, false, nullptr, false, true, 256);   // [1, 3, Wt/4 - 1, 256]
-    if (!ar.dry) HIPCHK(launch_rowmean3_gather(c6.p, c6.W, 256, descs, first, count, seq_v, c->cur));
+    if (!ar.dry) HIPCHK(launch_rowmean3_gather(c6.p, c6.W, 256, descs, first, count, seq_v, rec_mode(c), c->cur));
 }
 
 // Sequence half of the recogniser over the POOLED time steps of every bucket (rows = sum n_i*T_i, padded to x256):
@@ -110,17 +116,19 @@ static void crnn_features_wide(bbocr_ctx* c, const uint16_t* wide, int Wt, const
 void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, int ntiles, float* logits) {
     c->prof_group = 1;
     c->arena.dry = false;
-    c->seq_xp.ensure(rows_pad * 2048 * 2);
-    c->seq_h.ensure(rows_pad * 512 * 2);
-    c->seq_lin.ensure(rows_pad * 256 * 2);
+    const bool sp = rec_split(c);
+    const int m = rec_mul(c);
+    c->seq_xp.ensure(rows_pad * 2048 * (sp ? 4 : 2));            // exact mode: the input projection stays fp32
+    c->seq_h.ensure(rows_pad * 512 * 2 * m);
+    c->seq_lin.ensure(rows_pad * 256 * 2 * m);
     const int Hh = (int)(rows_pad / 256);
-    Act cur{(uint16_t*)c->seq_v.p, 1, Hh, 256, 256};
+    Act cur{(uint16_t*)c->seq_v.p, 1, Hh, 256, 256 * m};
     for (int l = 0; l < 2; ++l) {
-        run_conv(c, c->xproj[l], cur, false, nullptr, false, false, c->seq_xp.p, 2048, 2048, false);
-        HIPCHK(launch_lstm((const uint16_t*)c->seq_xp.p, c->whh[l], (uint16_t*)c->seq_h.p, tiles_dev, ntiles, c->stream));
-        Act hh{(uint16_t*)c->seq_h.p, 1, Hh, 256, 512};
+        run_conv(c, c->xproj[l], cur, false, nullptr, false, false, c->seq_xp.p, 2048, 2048, sp);
+        HIPCHK(launch_lstm(c->seq_xp.p, c->whh[l], (uint16_t*)c->seq_h.p, tiles_dev, ntiles, rec_mode(c), c->whh_scale[l], c->stream));
+        Act hh{(uint16_t*)c->seq_h.p, 1, Hh, 256, 512 * m};
         uint16_t* dst = (uint16_t*)(l == 0 ? c->seq_lin.p : c->seq_v.p);
-        run_conv(c, c->lin[l], hh, false, nullptr, false, false, dst, 256, 256, false);
+        run_conv(c, c->lin[l], hh, false, nullptr, false, false, dst, 256 * m, 256, false);
         cur.p = dst;
     }
     run_conv(c, c->pred, cur, false, nullptr, false, false, logits, 112, 112, true);
@@ -182,7 +190,7 @@ static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, con
         uint16_t* wide = c->arena.alloc<uint16_t>((size_t)64 * Wt);
         if (pass == 1)
             HIPCHK(launch_crops(gray, H, W, dd, 0, n, 0, part.any_warp, part.any_tall, (uint8_t*)c->crop_wscratch.p, (uint8_t*)c->crop_scratch.p,
-                                (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, wide, 2, c->stream, Wt, REC_GAP));
+                                (uint8_t*)c->crop_hscratch.p, (const uint8_t*)c->crop_luts.p, wide, 2, c->stream, Wt, REC_GAP, rec_mode(c)));
         crnn_features_wide(c, wide, Wt, dd, 0, n, (uint16_t*)c->seq_v.p);
         if (pass == 0) c->arena.buf.ensure(c->arena.off);
     }
@@ -293,7 +301,7 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
         rec_plan_part(jobs, sub, 0, 0, part);
         for (size_t i = 0; i < part.order.size(); ++i) part.order[i] = ks[part.order[i]];
         auto t0 = clk::now();
-        c->seq_v.ensure(align_up(part.rows, 256) * 256 * 2);
+        c->seq_v.ensure(align_up(part.rows, 256) * 256 * 2 * rec_mul(c));
         rec_launch_part(c, gray, H, W, part, c->crop_desc, stage_a);
         c->times[3] += (float)ms_since(t0);
         RecRun run;
@@ -382,7 +390,7 @@ void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B, int H,
     c->crop_hscratch.ensure(std::max<size_t>((size_t)((double)e.a_total * grow), 16));
     c->crop_wscratch.ensure(std::max<size_t>((size_t)((double)e.w_total * grow), 16));
     c->crop_luts.ensure(256);
-    c->seq_v.ensure(align_up((size_t)((double)e.part.rows * grow), 256) * 256 * 2);
+    c->seq_v.ensure(align_up((size_t)((double)e.part.rows * grow), 256) * 256 * 2 * rec_mul(c));
     auto t0 = clk::now();
     rec_launch_part(c, gray, H, W, e.part, c->crop_desc, true);
     c->times[3] += (float)ms_since(t0);
@@ -480,7 +488,7 @@ void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, cons
         RecRun run;
         rec_add_tables(run, early->part);
         if (early->part.rows + part2.rows <= rec_max_rows(c)) {
-            c->seq_v.ensure_keep(align_up(early->part.rows + part2.rows, 256) * 256 * 2, early->part.rows * 256 * 2);
+            c->seq_v.ensure_keep(align_up(early->part.rows + part2.rows, 256) * 256 * 2 * rec_mul(c), early->part.rows * 256 * 2 * rec_mul(c));
             auto t0 = clk::now();
             rec_launch_part(c, gray, H, W, part2, c->crop_desc2, true);
             c->times[3] += (float)ms_since(t0);

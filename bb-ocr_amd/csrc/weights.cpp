@@ -25,8 +25,9 @@ static void fold_conv(const TensorMap& tm, const std::string& conv, const std::s
     }
 }
 
-ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil) {
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el) {
     ConvPlan p;
+    p.el = el;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad_h = pad; p.pad_w = pad; p.dil = dil;
     p.Cin_pad = cdiv(Cin, 32) * 32;
     p.BN = conv_plan_bn(Cout);
@@ -43,6 +44,39 @@ void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const s
     p.d_b = upload(c, bp);
 }
 
+// Split-fp16 plan of the exact recogniser mode: activations arrive as [hi | lo] pairs of fp16 tensors and the launch reads the channel
+// sequence [a_hi | 2048 a_lo | a_hi] (in0 = the pair, in1 = its hi half again), so the packed weights are [w_hi | w_hi / 2048 | w_lo]
+// along Cin: ONE launch accumulates a_hi w_hi + a_lo w_hi + a_hi w_lo in fp32 (the dropped lo*lo term is 2^-22 relative).  The weights are
+// scaled by a power of two so that their largest magnitude sits in [512, 1024): w_lo = fp16(w 2^s - w_hi) then stays in fp16's
+// normal range for every weight that matters; the epilogue multiplies the accumulators by 2^-s (exact).
+static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int KH, int KW, int pad, const std::vector<float>& w,
+                              const std::vector<float>& b) {
+    if (Cin % 32) fail(BBOCR_ERR_INTERNAL, "split plan: Cin must be a multiple of 32");
+    const int taps = KH * KW;
+    float mx = 0.f;
+    for (float v : w) mx = std::max(mx, std::fabs(v));
+    int s = 0;
+    if (mx > 0.f) s = 9 - (int)std::floor(std::log2((double)mx));          // 2^9 <= mx * 2^s < 2^10
+    s = std::max(-14, std::min(24, s));
+    const float sc = std::ldexp(1.f, s);
+    std::vector<float> w3((size_t)Cout * 3 * Cin * taps);
+    for (int o = 0; o < Cout; ++o)
+        for (int i = 0; i < Cin; ++i)
+            for (int t = 0; t < taps; ++t) {
+                const float v = w[((size_t)o * Cin + i) * taps + t] * sc;
+                const float hi = f16_to_f32_host(f32_to_f16_host(v));
+                const float lo = f16_to_f32_host(f32_to_f16_host(v - hi));
+                float* row = w3.data() + (size_t)o * 3 * Cin * taps;
+                row[((size_t)i) * taps + t] = hi;
+                row[((size_t)Cin + i) * taps + t] = hi * (1.f / SPLIT_LO_SCALE);     // the lo activations are stored x 2048
+                row[((size_t)2 * Cin + i) * taps + t] = lo;
+            }
+    p = make_plan(3 * Cin, Cout, KH, KW, pad, 1, 1);
+    p.acc_scale = std::ldexp(1.f, -s);
+    p.split = 1;
+    upload_plan(c, p, w3, b);
+}
+
 // 1x1 conv over a channel concat [y (Cy) | skip (Cs)], BN folded, split into the two column blocks
 static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, ConvPlan& ps, const std::string& conv, const std::string& bn, int Cy,
                            int Cs, int Cout) {
@@ -53,17 +87,21 @@ static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, Conv
         std::copy(w.begin() + (size_t)o * (Cy + Cs), w.begin() + (size_t)o * (Cy + Cs) + Cy, wy.begin() + (size_t)o * Cy);
         std::copy(w.begin() + (size_t)o * (Cy + Cs) + Cy, w.begin() + (size_t)(o + 1) * (Cy + Cs), ws.begin() + (size_t)o * Cs);
     }
-    py = make_plan(Cy, Cout, 1, 1, 0, 1);
+    py = make_plan(Cy, Cout, 1, 1, 0, 1, det_el(c));
     upload_plan(c, py, wy, zero);
-    ps = make_plan(Cs, Cout, 1, 1, 0, 1);
+    ps = make_plan(Cs, Cout, 1, 1, 0, 1, det_el(c));
     upload_plan(c, ps, ws, b);
 }
 
 static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std::string& conv, const std::string& bn, int Cin, int Cout,
-                       int K, int pad, int dil) {
-    p = make_plan(Cin, Cout, K, K, pad, dil);
+                       int K, int pad, int dil, int el, bool split = false) {
     std::vector<float> w, b;
     fold_conv(tm, conv, bn, Cout, Cin, K * K, w, b);
+    if (split) {
+        upload_split_plan(c, p, Cin, Cout, K, K, pad, w, b);
+        return;
+    }
+    p = make_plan(Cin, Cout, K, K, pad, dil, el);
     upload_plan(c, p, w, b);
 }
 
@@ -78,36 +116,34 @@ void load_craft(bbocr_ctx* c, const TensorMap& tm) {
         std::vector<float> w, b;
         fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);
         std::vector<uint16_t> pk(2 * 4 * 64 * 8);
-        pack_conv1_1_weights(w.data(), pk.data());
-        c->c11_w = upload(c, pk);
-        pack_conv1_1_weights_fused(w.data(), pk.data());
+        pack_conv1_1_weights_fused(w.data(), pk.data(), det_el(c));
         c->c11_wf = upload(c, pk);
         c->c11_b = upload(c, b);
     }
-    load_layer(c, tm, c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1);
-    load_layer(c, tm, c->conv2_1, "basenet.slice1.7", "basenet.slice1.8", 64, 128, 3, 1, 1);
-    load_layer(c, tm, c->conv2_2, "basenet.slice1.10", "basenet.slice1.11", 128, 128, 3, 1, 1);
-    load_layer(c, tm, c->conv3_1, "basenet.slice2.14", "basenet.slice2.15", 128, 256, 3, 1, 1);
-    load_layer(c, tm, c->conv3_2, "basenet.slice2.17", "basenet.slice2.18", 256, 256, 3, 1, 1);
-    load_layer(c, tm, c->conv3_3, "basenet.slice3.20", "basenet.slice3.21", 256, 256, 3, 1, 1);
-    load_layer(c, tm, c->conv4_1, "basenet.slice3.24", "basenet.slice3.25", 256, 512, 3, 1, 1);
-    load_layer(c, tm, c->conv4_2, "basenet.slice3.27", "basenet.slice3.28", 512, 512, 3, 1, 1);
-    load_layer(c, tm, c->conv4_3, "basenet.slice4.30", "basenet.slice4.31", 512, 512, 3, 1, 1);
-    load_layer(c, tm, c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1);
-    load_layer(c, tm, c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1);
-    load_layer(c, tm, c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6);
-    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1);
-    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1);
-    load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1);
+    load_layer(c, tm, c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv2_1, "basenet.slice1.7", "basenet.slice1.8", 64, 128, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv2_2, "basenet.slice1.10", "basenet.slice1.11", 128, 128, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv3_1, "basenet.slice2.14", "basenet.slice2.15", 128, 256, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv3_2, "basenet.slice2.17", "basenet.slice2.18", 256, 256, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv3_3, "basenet.slice3.20", "basenet.slice3.21", 256, 256, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv4_1, "basenet.slice3.24", "basenet.slice3.25", 256, 512, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv4_2, "basenet.slice3.27", "basenet.slice3.28", 512, 512, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv4_3, "basenet.slice4.30", "basenet.slice4.31", 512, 512, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6, det_el(c));
+    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1, det_el(c));
+    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1, det_el(c));
+    load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1, det_el(c));
     load_split_1x1(c, tm, c->up2y, c->up2s, "upconv2.conv.0", "upconv2.conv.1", 256, 512, 256);
-    load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1);
+    load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1, det_el(c));
     load_split_1x1(c, tm, c->up3y, c->up3s, "upconv3.conv.0", "upconv3.conv.1", 128, 256, 128);
-    load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1);
+    load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1, det_el(c));
     load_split_1x1(c, tm, c->up4y, c->up4s, "upconv4.conv.0", "upconv4.conv.1", 64, 128, 64);
-    load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1);
-    load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1);
-    load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
-    load_layer(c, tm, c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1);
+    load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1, det_el(c));
+    load_layer(c, tm, c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1, det_el(c));
     {
         const float* w1 = tm.get("conv_cls.6.weight", 256);
         const float* b1 = tm.get("conv_cls.6.bias", 16);
@@ -122,7 +158,7 @@ void load_craft(bbocr_ctx* c, const TensorMap& tm) {
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int o = l & 15, k = 8 * (l >> 4) + j;
-                fr[l * 8 + j] = f32_to_bf16_host(k < 16 ? w1[o * 16 + k] : 0.f);
+                fr[l * 8 + j] = f32_to_el_host(det_el(c), k < 16 ? w1[o * 16 + k] : 0.f);
             }
         c->cls_tail_frag = upload(c, fr);
     }
@@ -140,12 +176,12 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         std::copy(b, b + 32, t.begin() + 288);
         c->r0_wb = upload(c, t);
     }
-    load_layer(c, tm, c->r1, fe + "3", "", 32, 64, 3, 1, 1);
-    load_layer(c, tm, c->r2, fe + "6", "", 64, 128, 3, 1, 1);
-    load_layer(c, tm, c->r3, fe + "8", "", 128, 128, 3, 1, 1);
-    load_layer(c, tm, c->r4, fe + "11", fe + "12", 128, 256, 3, 1, 1);
-    load_layer(c, tm, c->r5, fe + "14", fe + "15", 256, 256, 3, 1, 1);
-    load_layer(c, tm, c->r6, fe + "18", "", 256, 256, 2, 0, 1);
+    load_layer(c, tm, c->r1, fe + "3", "", 32, 64, 3, 1, 1, rec_el(c), rec_split(c));
+    load_layer(c, tm, c->r2, fe + "6", "", 64, 128, 3, 1, 1, rec_el(c), rec_split(c));
+    load_layer(c, tm, c->r3, fe + "8", "", 128, 128, 3, 1, 1, rec_el(c), rec_split(c));
+    load_layer(c, tm, c->r4, fe + "11", fe + "12", 128, 256, 3, 1, 1, rec_el(c), rec_split(c));
+    load_layer(c, tm, c->r5, fe + "14", fe + "15", 256, 256, 3, 1, 1, rec_el(c), rec_split(c));
+    load_layer(c, tm, c->r6, fe + "18", "", 256, 256, 2, 0, 1, rec_el(c), rec_split(c));
     for (int l = 0; l < 2; ++l) {
         const std::string sm = "SequenceModeling." + std::to_string(l) + ".";
         // input projection of both directions as one 1x1 conv with the channel permutation the LSTM kernel reads
@@ -162,23 +198,38 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
                     b[dst] = bih[src] + bhh[src];
                 }
         }
-        c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1);
-        upload_plan(c, c->xproj[l], w, b);
         const float* hf = tm.get(sm + "rnn.weight_hh_l0", (size_t)1024 * 256);
         const float* hb = tm.get(sm + "rnn.weight_hh_l0_reverse", (size_t)1024 * 256);
-        std::vector<uint16_t> pk(lstm_whh_packed_elems());
-        pack_lstm_whh8(hf, hb, pk.data());
-        c->whh[l] = upload(c, pk);
+        if (rec_split(c)) {
+            upload_split_plan(c, c->xproj[l], 256, 2048, 1, 1, 0, w, b);
+            std::vector<uint16_t> pk(lstm_whh_split_packed_elems());
+            c->whh_scale[l] = pack_lstm_whh_split(hf, hb, pk.data());
+            c->whh[l] = upload(c, pk);
+        } else {
+            c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1, rec_el(c));
+            upload_plan(c, c->xproj[l], w, b);
+            std::vector<uint16_t> pk(lstm_whh_packed_elems());
+            pack_lstm_whh8(hf, hb, pk.data(), rec_el(c));
+            c->whh[l] = upload(c, pk);
+        }
         std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
         std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);
-        c->lin[l] = make_plan(512, 256, 1, 1, 0, 1);
-        upload_plan(c, c->lin[l], lw, lb);
+        if (rec_split(c)) {
+            upload_split_plan(c, c->lin[l], 512, 256, 1, 1, 0, lw, lb);
+        } else {
+            c->lin[l] = make_plan(512, 256, 1, 1, 0, 1, rec_el(c));
+            upload_plan(c, c->lin[l], lw, lb);
+        }
     }
     {
         std::vector<float> pw(tm.get("Prediction.weight", (size_t)97 * 256), tm.get("Prediction.weight", (size_t)97 * 256) + 97 * 256);
         std::vector<float> pb(tm.get("Prediction.bias", 97), tm.get("Prediction.bias", 97) + 97);
-        c->pred = make_plan(256, 97, 1, 1, 0, 1);
-        upload_plan(c, c->pred, pw, pb);
+        if (rec_split(c)) {
+            upload_split_plan(c, c->pred, 256, 97, 1, 1, 0, pw, pb);
+        } else {
+            c->pred = make_plan(256, 97, 1, 1, 0, 1, rec_el(c));
+            upload_plan(c, c->pred, pw, pb);
+        }
     }
     c->crnn_loaded = true;
 }

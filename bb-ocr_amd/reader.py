@@ -204,7 +204,7 @@ class Reader:
     def __init__(self, lang_list, gpu=True, model_storage_directory=None, user_network_directory=None,
                  detect_network="craft", recog_network="standard", download_enabled=True, detector=True, recognizer=True,
                  verbose=True, quantize=True, cudnn_benchmark=False, weights=None, device_index=None, det_sub_batch=0,
-                 rec_max_cols=0, **_ignored):
+                 rec_max_cols=0, precision="bf16", **_ignored):
         import torch
 
         if list(lang_list) != ["en"]:
@@ -218,7 +218,11 @@ class Reader:
         self.device = f"cuda:{self.device_index}"
         self._lib = _lib.load()
         self._lock = threading.Lock()
-        cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols))
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
+        self.precision = precision
+        cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols),
+                                precision=_lib.PRECISIONS[precision])
         h = C.c_void_p()
         rc = self._lib.bbocr_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -110,14 +110,16 @@ def designed_craft_state(seed: int = 0) -> dict:
     return sd
 
 
-def synthetic_crnn_state(seed: int = 0, logit_gain: float = 60.0, ih_gain: float = 8.0, hh_gain: float = 2.0,
+def synthetic_crnn_state(seed: int = 0, logit_gain: float = 60.0, ih_gain: float = 8.0, hh_gain: float = 1.0,
                          lin_gain: float = 4.0) -> dict:
     """Seeded random CRNN (english_g2 architecture: 1x64xW -> T x 97).
 
     PyTorch-default initialisation makes a random CRNN emit one constant class with ~1/97
     confidence, which would send every box through the contrast-retry pass.  The gains widen the
-    recurrent / linear / prediction weights so the arg-max varies along the sequence and the
-    confidence lands around 0.2-0.4 (above ``contrast_ths`` for most boxes), like a trained model.
+    input / linear / prediction weights so the arg-max varies along the sequence and the
+    confidence lands around 0.1-0.3 (above ``contrast_ths`` for most boxes), like a trained model.
+    The recurrent weights keep PyTorch's scale (``hh_gain`` 1): a wider W_hh makes the random recurrence
+    chaotic, i.e. an amplifier of rounding noise that no trained recogniser is.
     """
     rng = np.random.default_rng(seed + 1000)
     sd = {}

@@ -41,8 +41,17 @@ typedef struct bbocr_config {
     int device;         /* HIP device ordinal */
     int det_sub_batch;  /* pages per detector pass; 0 = auto (<= 64 pages / 96 GB of activations, short last pass) */
     int rec_max_cols;   /* pixel columns (4 per pooled time step) whose sequence stage runs as one pass; 0 = default (6,000,000) */
-    int reserved[5];
+    int precision;      /* arithmetic of the two networks (fixed per context: the weights are packed for it at bbocr_load_weights):
+                         *   BBOCR_PREC_BF16  (0, default) bf16 MFMA operands and stored activations, fp32 accumulation;
+                         *   BBOCR_PREC_FP16  (1) the same kernels on IEEE fp16 operands (v_mfma_f32_16x16x32_f16): 8x finer rounding,
+                         *                        range 6e-8 .. 65504 -- BASELINE.json configs[4] ("fp16 MFMA conv path");
+                         *   BBOCR_PREC_EXACT (2) detector as FP16; recogniser in split fp16: every activation and weight is a pair
+                         *                        hi + lo of fp16 values (22 significand bits) and every product runs as the three MFMA
+                         *                        terms hi*hi + lo*hi + hi*lo accumulated in fp32, LSTM state and gates in fp32 --
+                         *                        the mode whose decoded TEXT equals the fp32 CPU path's (3x the recogniser's MFMA work) */
+    int reserved[4];
 } bbocr_config;
+enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2 };
 
 /* One tensor of an upstream state-dict (easyocr/craft.py::CRAFT or easyocr/model/vgg_model.py::Model key names,
  * optional "module." prefix), fp32, host memory, C-contiguous.  Replaces torch.load + load_state_dict in
@@ -164,13 +173,16 @@ int bbocr_host_ctc_beam(const float* probs, int n, int T, int C, int cs, int bea
 
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
- * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout).
+ * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout).  With
+ * bbocr_config::precision >= BBOCR_PREC_FP16 "bf16" reads "fp16" throughout (the context's element type).
  * pool_mode 1/2 fuses MaxPool2d(2,2) / MaxPool2d((2,1),(2,1)) (optionally after ReLU: pool_relu) into the epilogue and
  * writes bf16 [N,OH/2,OW/2 or OW,Cout_store] to dev_pool_out; dev_out may then be NULL (pooled output only). */
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                     int KH, int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
                     uint16_t* dev_pool_out);
-/* recogniser network only: crops bf16 [n,64,imgW] (device, already normalised) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
+/* recogniser network only: crops [n,64,imgW] (device, 16-bit elements of the context's precision: bf16 / fp16 values already
+ * normalised to [-1, 1]; BBOCR_PREC_EXACT: CODES, 0 = padding zero, 1 + grey level otherwise, from which the first layer rebuilds the
+ * fp32 input ((g/255 - 0.5)/0.5) exactly) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);
 /* CTC decode of logits fp32 [n,T,cs]: host outputs text_off [n+1], text_idx (<= n*T), conf [n]; ignore_mask: 4 x 32-bit class mask
  * (bbocr_params::ignore_mask) or NULL; beam_width <= 0: greedy, > 0: ctcBeamSearch with that width (bbocr_params::decoder) */

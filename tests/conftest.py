@@ -55,3 +55,57 @@ def reader(states):
     r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states)
     yield r
     r.close()
+
+
+@pytest.fixture(scope="session")
+def reader_fp16(states):
+    """bbocr_config::precision = BBOCR_PREC_FP16: both networks on fp16 MFMA operands (BASELINE.json configs[4])."""
+    import bb_ocr_amd
+
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="fp16")
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
+def reader_exact(states):
+    """BBOCR_PREC_EXACT: fp16 detector, split-fp16 recogniser -- the mode whose decoded text must equal the fp32 CPU path's."""
+    import bb_ocr_amd
+
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="exact")
+    yield r
+    r.close()
+
+
+class LogitTap:
+    """Wraps an OracleReader so that the logits of every recogniser call are kept: the top-2 margins tell where an arg-max is
+    numerically decidable (a character may differ from the oracle only where the oracle's own margin is below the noise
+    bound of the arithmetic under test)."""
+
+    def __init__(self, oracle_reader):
+        self.o = oracle_reader
+        self.calls = []
+
+    def __enter__(self):
+        self._orig = self.o._logits
+
+        def tapped(x):
+            lg = self._orig(x)
+            self.calls.append(lg)
+            return lg
+
+        self.o._logits = tapped
+        return self
+
+    def __exit__(self, *exc):
+        self.o._logits = self._orig
+
+    def min_margins(self):
+        """Per recogniser call (one box each with the reference's batch_size=1): min over time steps of (top1 - top2) / max |logit|."""
+        import numpy as np
+
+        out = []
+        for lg in self.calls:
+            v = np.sort(lg.reshape(-1, lg.shape[-1]), axis=1)
+            out.append(float(((v[:, -1] - v[:, -2]) / max(np.abs(lg).max(), 1e-30)).min()))
+        return out
