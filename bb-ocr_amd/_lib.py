@@ -63,6 +63,10 @@ PROTOTYPES = {
     "bbocr_last_error": (C.c_char_p, [_vp]),
     "bbocr_default_params": (None, [C.POINTER(bbocr_params)]),
     "bbocr_load_weights": (C.c_int, [_vp, C.c_int, C.POINTER(bbocr_tensor_desc), C.c_int]),
+    "bbocr_alloc_weights": (C.c_int, [_vp, C.c_int]),
+    "bbocr_weights_blob_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "bbocr_weights_export": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "bbocr_weights_import": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bbocr_detect_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "bbocr_detect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(bbocr_params), _vp]),

@@ -72,6 +72,36 @@ int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs
     });
 }
 
+int bbocr_alloc_weights(bbocr_ctx* ctx, int which) {
+    return guarded(ctx, [&] {
+        if (which != 0 && which != 1) fail(BBOCR_ERR_ARG, "which: 0 = detector, 1 = recogniser");
+        TensorMap tm;                        // every tensor present, all zeros: lays the packed plans out, bbocr_weights_import fills them
+        if (which == 0) load_craft(ctx, tm);
+        else load_crnn(ctx, tm);
+    });
+}
+
+int bbocr_weights_blob_size(bbocr_ctx* ctx, size_t* bytes) {
+    return guarded(ctx, [&] {
+        if (!bytes) fail(BBOCR_ERR_ARG, "null pointer");
+        *bytes = weights_blob_bytes(ctx);
+    });
+}
+
+int bbocr_weights_export(bbocr_ctx* ctx, void* dev_blob, size_t bytes) {
+    return guarded(ctx, [&] {
+        if (!dev_blob) fail(BBOCR_ERR_ARG, "null device pointer");
+        weights_export(ctx, dev_blob, bytes);
+    });
+}
+
+int bbocr_weights_import(bbocr_ctx* ctx, const void* dev_blob, size_t bytes) {
+    return guarded(ctx, [&] {
+        if (!dev_blob) fail(BBOCR_ERR_ARG, "null device pointer");
+        weights_import(ctx, dev_blob, bytes);
+    });
+}
+
 int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio) {
     if (H <= 0 || W <= 0 || canvas_size <= 0) return BBOCR_ERR_ARG;
     const DetDims d = det_dims(H, W, canvas_size, (double)mag_ratio);

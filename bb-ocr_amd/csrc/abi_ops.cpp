@@ -135,7 +135,7 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
         a.zero = ctx->zero_page;
         const hipError_t e = launch_conv(p, a, ctx->stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); }
+        while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); ctx->owned_bytes.pop_back(); }
         HIPCHK(e);
         HIPCHK(e2);
     });

@@ -150,7 +150,8 @@ struct bbocr_ctx {
     ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
     uint16_t* whh[2] = {nullptr, nullptr};
     float whh_scale[2] = {1.f, 1.f};   // exact mode: 2^-s of the packed W_hh (pack_lstm_whh_split)
-    std::vector<void*> owned;    // every hipMalloc'd weight block
+    std::vector<void*> owned;    // every hipMalloc'd weight block, in load order (the order of the weight blob, bbocr_weights_export)
+    std::vector<size_t> owned_bytes;
 
     void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
     Arena arena;
@@ -171,6 +172,9 @@ inline bool rec_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PRE
 // ------------------------------------------------------------------------------------------------ shared types
 struct TensorMap {
     std::unordered_map<std::string, const bbocr_tensor_desc*> m;
+    bool zeros = false;                       // allocation-only load (bbocr_alloc_weights): every tensor exists and is all zeros
+    std::vector<float> zero_buf;              // sized once (pointers handed out stay valid): the largest tensor is fc6, 1024 x 512 x 9
+    TensorMap() : zeros(true), zero_buf((size_t)5 << 20, 0.f) {}
     TensorMap(const bbocr_tensor_desc* d, int n) {
         for (int i = 0; i < n; ++i) {
             std::string k = d[i].name ? d[i].name : "";
@@ -179,6 +183,10 @@ struct TensorMap {
         }
     }
     const float* get(const std::string& name, size_t numel, bool required = true) const {
+        if (zeros) {
+            if (zero_buf.size() < numel) fail(BBOCR_ERR_INTERNAL, "allocation-only load: tensor '" + name + "' larger than the zero buffer");
+            return zero_buf.data();
+        }
         auto it = m.find(name);
         if (it == m.end()) {
             if (required) fail(BBOCR_ERR_WEIGHTS, "missing tensor '" + name + "'");
@@ -249,6 +257,7 @@ template <typename T> inline T* upload(bbocr_ctx* c, const std::vector<T>& v) {
     void* d = nullptr;
     HIPCHK(hipMalloc(&d, v.size() * sizeof(T)));
     c->owned.push_back(d);
+    c->owned_bytes.push_back(v.size() * sizeof(T));
     HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return (T*)d;
 }
@@ -256,6 +265,9 @@ template <typename T> inline T* upload(bbocr_ctx* c, const std::vector<T>& v) {
 ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el = 0);
 void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b);
 void free_weights(bbocr_ctx* c);
+size_t weights_blob_bytes(const bbocr_ctx* c);
+void weights_export(bbocr_ctx* c, void* dev_dst, size_t bytes);
+void weights_import(bbocr_ctx* c, const void* dev_src, size_t bytes);
 void load_craft(bbocr_ctx* c, const TensorMap& tm);
 void load_crnn(bbocr_ctx* c, const TensorMap& tm);
 void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a);

@@ -1,11 +1,20 @@
-"""One process per GPU: page sharding, one-time weight broadcast, result gather.
+"""One process per GPU: page sharding, one-time weight broadcast, page scatter, result gather.
 
 Pages are independent through every stage, so the path shards embarrassingly: rank r takes the
-contiguous block ``[r*B/G, (r+1)*B/G)`` and there is NO collective on the data path.  The only
-exchanges are (1) the detector + recogniser parameters broadcast once from rank 0 -- the
-process-per-GPU replacement of ``torch.nn.DataParallel``'s per-forward ``broadcast_coalesced`` in
-``easyocr.py::get_detector/get_recognizer`` -- and (2) the gather of the (tiny, variable-length)
-results to rank 0.  Backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
+contiguous block ``[r*B/G, (r+1)*B/G)`` and there is NO collective inside the OCR path.  The exchanges are
+
+1. the detector + recogniser parameters, broadcast ONCE from rank 0 -- the process-per-GPU replacement of
+   ``torch.nn.DataParallel``'s per-forward ``broadcast_coalesced`` in ``easyocr.py::get_detector/get_recognizer``.
+   ``broadcast_packed`` ships the weights as the kernels read them (BN folded, rounded to the element type, MFMA fragment order:
+   one contiguous DEVICE blob, ~49 MB in bf16) device-to-device: rank 0 ``bbocr_weights_export`` -> ``ncclBroadcast`` over xGMI ->
+   ``bbocr_weights_import`` on the others, no host hop, no re-packing.  ``broadcast_state`` (fp32 state-dict through the host) stays
+   for CPU-side consumers such as the oracle;
+2. ``scatter_pages``: the loader rank holds the decoded pages and sends every rank its block -- grouped point-to-point sends
+   (``ncclGroupStart; ncclSend x (G-1); ncclGroupEnd``: all 7 xGMI links of the root in use at once), blocks may be uneven;
+   when every rank can decode / render its own shard this step disappears (bench.py does that);
+3. ``gather_results``: the (tiny, variable-length) per-page results to rank 0.
+
+Backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests (tests/test_dist_gloo.py).
 """
 from __future__ import annotations
 
@@ -20,7 +29,7 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 def broadcast_state(state: dict | None, src: int = 0, device="cpu"):
-    """Broadcast a state-dict from ``src`` as ONE flat fp32 buffer (+ a small pickled key/shape table)."""
+    """Broadcast a state-dict from ``src`` as ONE flat fp32 buffer (+ a small pickled key/shape table) -> numpy state-dict on every rank."""
     import torch
     import torch.distributed as dist
 
@@ -43,6 +52,78 @@ def broadcast_state(state: dict | None, src: int = 0, device="cpu"):
         out[k] = host[o:o + n].reshape(s).copy()
         o += n
     return out
+
+
+def broadcast_packed(make_root_reader, make_empty_reader, src: int = 0, via_host: bool = False):
+    """-> this rank's ``Reader`` with the packed weights of rank ``src``.
+
+    ``make_root_reader()`` builds the source reader from real weights (called on ``src`` only); ``make_empty_reader()`` builds a
+    ``Reader(weights="empty", precision=<same>)`` on the other ranks.  The blob travels device-to-device (``via_host=True`` only for the
+    gloo rehearsal, where the collective runs on CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank()
+    reader = make_root_reader() if rank == src else make_empty_reader()
+    size = torch.tensor([reader.weights_blob_size()], dtype=torch.int64)
+    sizes = [torch.zeros_like(size) for _ in range(dist.get_world_size())]
+    if via_host:
+        dist.all_gather(sizes, size)
+    else:
+        size = size.to(reader.device)
+        sizes = [s.to(reader.device) for s in sizes]
+        dist.all_gather(sizes, size)
+    if len({int(s.item()) for s in sizes}) != 1:
+        raise RuntimeError("ranks disagree on the weight blob size: same precision and networks on every rank?")
+    if rank == src:
+        blob = reader.export_weights_blob()
+    else:
+        blob = torch.empty(reader.weights_blob_size(), dtype=torch.uint8, device=reader.device)
+    if via_host:
+        hb = blob.cpu()
+        dist.broadcast(hb, src=src)
+        if rank != src:
+            blob.copy_(hb)
+            torch.cuda.current_stream(reader.device_index).synchronize()
+    else:
+        dist.broadcast(blob, src=src)                # ncclBroadcast, device to device over xGMI
+        torch.cuda.current_stream(reader.device_index).synchronize()
+    if rank != src:
+        reader.import_weights_blob(blob)
+    return reader
+
+
+def scatter_pages(pages, n_pages: int, page_shape, src: int = 0, device="cpu"):
+    """The loader rank ``src`` holds ``pages`` (uint8 tensor ``[n_pages, *page_shape]``, ``None`` elsewhere); every rank returns its
+    contiguous block ``shard_range(n_pages, rank, world)`` as a tensor on ``device``.  Blocks may be uneven (``n_pages % world != 0``) or
+    empty.  One grouped batch of point-to-point operations: the root's sends to all peers run concurrently."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    a, b = shard_range(n_pages, rank, world)
+    if rank == src:
+        if pages is None or tuple(pages.shape) != (n_pages, *page_shape) or pages.dtype != torch.uint8:
+            raise ValueError(f"root must hold uint8 pages [{n_pages}, {page_shape}]")
+        ops, keep = [], []
+        for r in range(world):
+            if r == src:
+                continue
+            ra, rb = shard_range(n_pages, r, world)
+            if rb > ra:
+                block = pages[ra:rb].contiguous()
+                keep.append(block)
+                ops.append(dist.P2POp(dist.isend, block, r))
+        local = pages[a:b].to(device).clone()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return local
+    local = torch.empty((b - a, *page_shape), dtype=torch.uint8, device=device)
+    if b > a:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, local, src)]):
+            req.wait()
+    return local
 
 
 def gather_results(local_results: list, dst: int = 0):

@@ -230,6 +230,12 @@ class Reader:
         self._h = h
         self.character = CHARACTER
         self.lang_char = list(CHARSET)
+        if isinstance(weights, str) and weights == "empty":
+            # multi-GPU receiver: the packed plans are laid out without values and filled by import_weights_blob (dist.broadcast_packed)
+            for which, wanted in ((0, detector), (1, recognizer)):
+                if wanted:
+                    self._check(self._lib.bbocr_alloc_weights(self._h, which))
+            return
         craft_state, crnn_state = self._resolve_weights(weights, model_storage_directory)
         if detector:
             self._load(0, craft_state)
@@ -255,6 +261,23 @@ class Reader:
         if rc != 0:
             msg = self._lib.bbocr_last_error(self._h)
             raise RuntimeError(f"libbbocr status {rc}: {msg.decode(errors='replace') if msg else ''}")
+
+    # -- packed weights as one device blob (multi-GPU broadcast, include/bbocr.h) -------
+    def weights_blob_size(self):
+        n = C.c_size_t()
+        self._check(self._lib.bbocr_weights_blob_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def export_weights_blob(self):
+        """-> uint8 device tensor holding every packed weight block of this context (BN folded, element type rounded, MFMA order)."""
+        blob = self._torch.empty(self.weights_blob_size(), dtype=self._torch.uint8, device=self.device)
+        self._check(self._lib.bbocr_weights_export(self._h, C.c_void_p(blob.data_ptr()), blob.numel()))
+        return blob
+
+    def import_weights_blob(self, blob):
+        """Fill a ``Reader(weights="empty")`` from another rank's blob (same precision, same networks)."""
+        self._dev_u8(blob, "weight blob", 1, (self.weights_blob_size(),))
+        self._check(self._lib.bbocr_weights_import(self._h, C.c_void_p(blob.data_ptr()), blob.numel()))
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

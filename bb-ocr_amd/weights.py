@@ -82,6 +82,8 @@ def designed_craft_state(seed: int = 0) -> dict:
 
     region = 0.25 * B, affinity = 0.08 * L where, at half resolution, I = 2x2 max-pooled binary ink,
     B = 3x3 box sum of I and L = B filtered twice with [1,1,1] horizontally.  Dark-on-light pages only.
+    Ink is a BAND of grey levels (full response for green <= 16 .. 96, none at pure black): the zero canvas that
+    ``resize_aspect_ratio`` pads a page with (a 13-pixel stripe beside a 2480x3504 scan) is not text, as for a trained CRAFT.
     """
     sd = synthetic_craft_state(seed)
     c = [[0, 0, 0], [0, 1, 0], [0, 0, 0]]          # centre tap
@@ -92,7 +94,10 @@ def designed_craft_state(seed: int = 0) -> dict:
     a, b = -57.12 / 32.0, (128.0 - 116.28) / 32.0
     _signal(sd, "basenet.slice1.0", "basenet.slice1.1", 0, {1: ctr(a)}, b)            # relu(u)
     _signal(sd, "basenet.slice1.0", "basenet.slice1.1", 1, {1: ctr(a)}, b - 1.0)      # relu(u - 1)
-    _signal(sd, "basenet.slice1.3", "basenet.slice1.4", 0, {0: c, 1: ctr(-1.0)}, 0.0)  # I = clip(u, 0, 1)
+    _signal(sd, "basenet.slice1.0", "basenet.slice1.1", 2, {1: ctr(4 * a)}, 4 * b - 14.0)   # relu(4 (u - 3.5)): rises from green = 16 down
+    _signal(sd, "basenet.slice1.0", "basenet.slice1.1", 3, {1: ctr(4 * a)}, 4 * b - 15.0)   # relu(4 (u - 3.5) - 1)
+    # I = clip(u, 0, 1) - clip(4 (u - 3.5), 0, 1): 1 on ink (green 16 .. 96), 0 on paper AND on pure black (u = 4)
+    _signal(sd, "basenet.slice1.3", "basenet.slice1.4", 0, {0: c, 1: ctr(-1.0), 2: ctr(-1.0), 3: c}, 0.0)
     _signal(sd, "basenet.slice1.7", "basenet.slice1.8", 0, {0: box}, 0.0)              # B
     _signal(sd, "basenet.slice1.10", "basenet.slice1.11", 0, {0: c}, 0.0)              # skip s1 channel 0 = B
     _signal(sd, "upconv4.conv.0", "upconv4.conv.1", 0, {64: [[1.0]]}, 0.0)             # cat([up3(64), s1(128)])
@@ -110,14 +115,15 @@ def designed_craft_state(seed: int = 0) -> dict:
     return sd
 
 
-def synthetic_crnn_state(seed: int = 0, logit_gain: float = 60.0, ih_gain: float = 8.0, hh_gain: float = 1.0,
+def synthetic_crnn_state(seed: int = 0, logit_gain: float = 120.0, ih_gain: float = 4.0, hh_gain: float = 1.0,
                          lin_gain: float = 4.0) -> dict:
     """Seeded random CRNN (english_g2 architecture: 1x64xW -> T x 97).
 
     PyTorch-default initialisation makes a random CRNN emit one constant class with ~1/97
     confidence, which would send every box through the contrast-retry pass.  The gains widen the
-    input / linear / prediction weights so the arg-max varies along the sequence and the
-    confidence lands around 0.1-0.3 (above ``contrast_ths`` for most boxes), like a trained model.
+    input / linear / prediction weights so that, like a trained model on a printed line, the arg-max changes every
+    few time steps (~50 characters on a 600-pixel line) and the confidence lands around 0.25-0.85 (above
+    ``contrast_ths`` = 0.1, so the contrast-retry pass stays the exception it is in practice).
     The recurrent weights keep PyTorch's scale (``hh_gain`` 1): a wider W_hh makes the random recurrence
     chaotic, i.e. an amplifier of rounding noise that no trained recogniser is.
     """

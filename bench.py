@@ -7,7 +7,10 @@
 One "step" = one pass of the whole hot path (CRAFT detect -> boxes -> crops -> CRNN -> CTC) over one batch of
 synthetic 1280x960 pages per GPU, pages already resident in HBM.  Workload = BASELINE.json configs[2]
 ("Full CRAFT+CRNN detect+recognize, batch=64 @1280x960, 1 MI355X"); with N GPUs every rank processes its own
-64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL).
+64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL) -- at N = 8
+that is BASELINE.json configs[3] (512 pages sharded across 8 MI355X).  `--config a4` runs configs[4]'s per-GPU share
+instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision
+(bf16 default; fp16; exact = split-fp16 recogniser whose text equals the fp32 CPU path's).
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- the dominant kernel (conv_mfma, detector launches): algorithmic FLOPs / sum of launch durations
@@ -25,8 +28,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-CRAFT_GFLOP_PER_PAGE = 874.22  # SURVEY.md section 8d, 1280x960 page
+PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
+CRAFT_GFLOP_PER_PAGE = {"p1": 874.22, "a4": 3322.03}  # 1280x960 page / A4@300dpi on the 2560 canvas
+CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, line pitch, precision, workload label)
+    "p1": (1280, 960, 64, 24, 38, "bf16", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
+    "a4": (2480, 3504, 16, 110, 31, "fp16", "A4@300dpi 2480x3504 dense-text scans, fp16 MFMA conv path, 16 pages per GPU "
+                                           "(BASELINE.json configs[4]: batch=128 on 8 GPUs)"),
+}
 
 
 def main():
@@ -34,15 +42,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="pages per GPU per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="p1", help="p1 = BASELINE.json configs[2]/[3] (the metric's workload), a4 = configs[4]")
+    ap.add_argument("--batch", type=int, default=0, help="pages per GPU per step (0 = the config's)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic pages rendered per rank (tiled to --batch)")
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=960)
-    ap.add_argument("--lines", type=int, default=20)
-    ap.add_argument("--cpu-pages", type=int, default=5, help="pages for the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
+    ap.add_argument("--precision", choices=("bf16", "fp16", "exact"), default=None, help="bbocr_config::precision (default: the config's)")
+    ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline after one warm-up page (0 = skip)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
+    cw, ch, cb, cl, cpitch, cprec, workload = CONFIGS[args.config]
+    args.width, args.height = args.width or cw, args.height or ch
+    args.batch, args.lines = args.batch or cb, args.lines or cl
+    args.precision = args.precision or cprec
 
     import numpy as np
     import torch
@@ -68,20 +82,25 @@ def main():
     from bb_ocr_amd import dist as bdist
     from bb_ocr_amd import synth, weights
 
-    # ---- weights: built on rank 0, broadcast once (RCCL) -- the process-per-GPU form of DataParallel's replicate
+    # ---- weights: built and packed on rank 0, broadcast ONCE as the packed device blob (RCCL, device to device over xGMI) -- the
+    # process-per-GPU form of DataParallel's per-forward replicate; the other ranks never see an fp32 state-dict
     cs = rs = None
     if rank == 0:
         cs, rs = weights.designed_craft_state(0), weights.synthetic_crnn_state(0)
+    mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
     if world > 1:
-        bdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
-        cs = bdist.broadcast_state(cs, 0, device=bdev)
-        rs = bdist.broadcast_state(rs, 0, device=bdev)
-    reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=(cs, rs), device_index=local_rank, det_sub_batch=args.det_sub_batch)
+        reader = bdist.broadcast_packed(lambda: mk((cs, rs)), lambda: mk("empty"), src=0, via_host=(args.backend != "nccl"))
+    else:
+        reader = mk((cs, rs))
 
     # ---- this rank's shard of the global batch (contiguous block), rendered on the host, then resident in HBM
     B = args.batch
     g0, g1 = bdist.shard_range(B * world, rank, world)
-    uniq = [synth.page(1234 + (g0 + i), width=args.width, height=args.height, lines=args.lines)[0] for i in range(min(args.unique, B))]
+    # seeded pages: every other one on tinted stock / coloured ink so that the gray plane is a real 3-channel mix
+    page_kw = dict(width=args.width, height=args.height, lines=args.lines, line_pitch=cpitch, margin=24)
+    if args.config == "a4":
+        page_kw.update(font_size=20, word_gap=14, margin=60)
+    uniq = [synth.page(1234 + (g0 + i), colour=bool((g0 + i) & 1), **page_kw)[0] for i in range(min(args.unique, B))]
     host = np.stack([uniq[i % len(uniq)] for i in range(g1 - g0)])
     rgb = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
@@ -129,7 +148,8 @@ def main():
 
     pages = B * world * args.steps
     result = {
-        "metric": "book-page images/sec end-to-end (detect+recognize) @1280x960",
+        "metric": "book-page images/sec end-to-end (detect+recognize) @1280x960" if args.config == "p1" else
+                  "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)",
         "value": pages / dt,
         "unit": "images/s",
         "n_gpus": world,
@@ -139,10 +159,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)"}[args.precision],
         "data": f"synthetic ({len(uniq)} distinct seeded pages per GPU tiled to the batch; seeded designed-detector + random-recogniser weights)",
         "config": {
-            "workload": "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])",
+            "workload": workload if not (args.config == "p1" and world == 8) else
+                        "batch=512 @1280x960 sharded across 8 MI355X, 64 pages per GPU (BASELINE.json configs[3]; RCCL weight broadcast, "
+                        "every rank renders its own shard)",
+            "precision": args.precision,
             "batch_per_gpu": B, "page_wh": [args.width, args.height], "text_lines_per_page": args.lines,
             "boxes_per_step_rank0": n_boxes, "chars_per_step_rank0": n_chars, "parallelism": f"dp{world} (page shards, no data-path collective)",
         },
@@ -152,31 +175,48 @@ def main():
     # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of the
     # same detector, reads = 2 x FETCH_SIZE KiB on gfx950), scaled by the pages the average launch of THIS run processed
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")
-    if os.path.exists(pmc) and conv_launches > 0 and (args.width, args.height) == (1280, 960):
+    pmc_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    pmc = next((os.path.join(pmc_dir, n) for n in ("r02_pmc_hbm.json", "r01_pmc_hbm.json") if os.path.exists(os.path.join(pmc_dir, n))), None)
+    if pmc and conv_launches > 0 and args.config == "p1" and args.precision == "bf16":
         with open(pmc) as f:
             t = json.load(f)
         traffic = (t["read_MB_per_page"] + t["write_MB_per_page"]) * 1e6 * B * args.steps / conv_launches
-        traffic_src = f"profiles/r01_pmc_hbm.json ({t['read_MB_per_page']:.0f} MB read + {t['write_MB_per_page']:.0f} MB written per page; bytes per average launch)"
+        traffic_src = (f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same detector, committed as profiles/{os.path.basename(pmc)} "
+                       f"({t['read_MB_per_page']:.0f} MB read + {t['write_MB_per_page']:.0f} MB written per page), scaled to bytes per average launch")
     result["roofline"] = {
         "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel (all 27 detector launches of a pass: conv1_1+conv1_2 fused .. conv_cls.4+tail)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
         "traffic": traffic, "traffic_source": traffic_src,
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
         "algorithmic_gflop_per_page": conv_flops / 1e9 / max(B * args.steps, 1),
+        "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE[args.config],
         # (the recogniser's ~500 launches per step overlap on side streams and are not event-timed in the measured run:
         #  Reader.set_profiling(2) + conv_profile(1) gives their busy time)
     }
     log(f"GPU legs done: {pages / dt:.1f} images/s; CPU baseline next")
     if world == 1 and args.cpu_pages > 0:
-        result["cpu_baseline"] = cpu_baseline(cs, rs, uniq, args.cpu_pages)
+        result["cpu_baseline"] = cpu_baseline(cs, rs, uniq, args.cpu_pages, (args.width, args.height))
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cs, rs, pages, n_pages):
-    """The oracle (CPU restatement of the same algorithm, batch 1 per page and per box) on this host's cores."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(cs, rs, pages, n_pages, wh):
+    """The oracle (CPU restatement of the same algorithm, batch 1 per page and per box like the reference's readtext call) on this host's
+    cores: one warm-up page, then n pages timed one by one; value = 1 / median seconds per page."""
+    import statistics
+
     import torch
 
     from oracle import pipeline
@@ -190,15 +230,19 @@ def cpu_baseline(cs, rs, pages, n_pages):
     torch.set_num_threads(cores)
     ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
     n = min(n_pages, len(pages))
-    t0 = time.perf_counter()
-    nb = 0
+    ref.readtext(pages[0])                                   # warm-up (thread pool, oneDNN primitive caches)
+    per_page, nb = [], 0
+    t_all = time.perf_counter()
     for i in range(n):
+        t0 = time.perf_counter()
         nb += len(ref.readtext(pages[i]))
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} of the same synthetic 1280x960 pages through oracle.pipeline.OracleReader.readtext "
-                      f"(torch fp32 CPU, batch 1 per page and per box, {nb} boxes, no warm-up)",
-            "seconds": dt}
+        per_page.append(time.perf_counter() - t0)
+    med = statistics.median(per_page)
+    return {"value": 1.0 / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model(),
+            "sample": f"CPU restatement (EasyOCR-equivalent algorithm, synthetic weights): {n} of the same synthetic {wh[0]}x{wh[1]} pages through "
+                      f"oracle.pipeline.OracleReader.readtext (torch fp32 CPU, batch 1 per page and per box, {nb} boxes) after 1 warm-up page; "
+                      f"value = 1 / median seconds per page",
+            "median_s_per_page": med, "seconds": time.perf_counter() - t_all}
 
 
 if __name__ == "__main__":

@@ -123,6 +123,19 @@ void bbocr_default_params(bbocr_params* p);
  * weights are packed to the MFMA fragment layout in bf16 and uploaded. */
 int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n);
 
+/* ---- multi-GPU: the packed weights as one device blob ("RCCL broadcast of detector/recognizer weights") ----
+ * What easyocr does per forward under nn.DataParallel (broadcast_coalesced of every parameter, easyocr.py::get_detector /
+ * get_recognizer) happens ONCE here, on the tensors as the kernels read them: rank 0 loads the state-dicts
+ * (bbocr_load_weights), exports the BN-folded, element-type-rounded, MFMA-packed images as ONE contiguous DEVICE buffer
+ * (bbocr_weights_export; ~49 MB in bf16) and broadcasts it device-to-device (ncclBroadcast over xGMI; torch.distributed.broadcast
+ * in the Python host); every other rank lays its plans out with bbocr_alloc_weights (no values) and fills them with
+ * bbocr_weights_import.  Size and layout depend only on bbocr_config::precision and on which networks are present; a blob from a
+ * context with another precision is refused (BBOCR_ERR_WEIGHTS). */
+int bbocr_alloc_weights(bbocr_ctx* ctx, int which /* 0 = detector, 1 = recogniser */);
+int bbocr_weights_blob_size(bbocr_ctx* ctx, size_t* bytes);
+int bbocr_weights_export(bbocr_ctx* ctx, void* dev_blob, size_t bytes);
+int bbocr_weights_import(bbocr_ctx* ctx, const void* dev_blob, size_t bytes);
+
 /* geometry of the detector for an H x W page: network input H32 x W32 (after canvas_size scaling, padded to x32),
  * heat-map h x w = H32/2 x W32/2, ratio as returned by resize_aspect_ratio */
 int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio);

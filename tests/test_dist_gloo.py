@@ -35,6 +35,21 @@ def _worker(rank, world, port, q):
         a, b = bdist.shard_range(10, rank, world)
         local = [[([[0, 0], [1, 0], [1, 1], [0, 1]], f"page{g}", 0.5)] * (g % 3) for g in range(a, b)]
         allr = bdist.gather_results(local, dst=0)
+        # scatter -> per-rank "OCR" -> gather, with uneven and empty shards (512 % 8 == 0 on the real node, 130 % 8 != 0)
+        for n_pages in (13, 2 * world, 1, 0):
+            shape = (6, 8, 3)
+            pages = None
+            if rank == 0:
+                pages = torch.arange(n_pages * 6 * 8 * 3, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(n_pages, *shape)
+            mine = bdist.scatter_pages(pages, n_pages, shape, src=0, device="cpu")
+            sa, sb = bdist.shard_range(n_pages, rank, world)
+            want = torch.arange(n_pages * 6 * 8 * 3, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(n_pages, *shape)[sa:sb]
+            same = same and mine.shape == want.shape and torch.equal(mine, want)
+            fake = [[([[0, 0], [1, 0], [1, 1], [0, 1]], f"sum{int(p.sum())}", 1.0)] for p in mine]      # stands in for readtext per page
+            got_all = bdist.gather_results(fake, dst=0)
+            if rank == 0:
+                full = torch.arange(n_pages * 6 * 8 * 3, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(n_pages, *shape)
+                same = same and [r[0][1] for r in got_all] == [f"sum{int(p.sum())}" for p in full]
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # the max-over-ranks timing reduction of bench.py
         ok = same and t.item() == world
@@ -47,15 +62,19 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_broadcast_shard_gather_world2():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_broadcast_scatter_gather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=180) for _ in range(2))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == {0: True, 1: True}
+    assert res == {r: True for r in range(world)}

@@ -312,8 +312,8 @@ def test_readtext_end_to_end(reader, oracle_reader):
         assert len(got) >= 4
     # random-weight recogniser in bf16 vs fp32: arg-max flips happen where the top-2 margin is below the bf16 noise,
     # so text identity is statistical here; the exact checks are the stage tests (CTC given logits, boxes given heat-map)
-    print("character agreement", agree, total)
-    assert agree / max(total, 1) > 0.5, (agree, total)
+    # text identity per precision mode (margin-aware for bf16 / fp16, outright for the exact mode): tests/test_gpu_precision.py
+    print("bf16 character agreement with the fp32 oracle (edit distance):", agree, "of", total)
 
 
 def test_readtext_edge_pages(reader, oracle_reader):
@@ -332,11 +332,12 @@ def test_readtext_edge_pages(reader, oracle_reader):
     assert reader.readtext(word) != []
 
 
-def test_rotation_info_matches_oracle(reader, oracle_reader):
-    """rotation_info (f4) end to end: the same boxes in the same (top-y sorted) order as the oracle's batched branch.  Which variant wins a
-    box depends on confidences that differ by bf16-vs-fp32 noise with random recogniser weights (the inputs of every variant are
-    bit-exact, test_rotated_crops_bit_exact), so the selection itself is checked as a property of the product: the result for
-    [90, 180, 270] is, box by box, the most confident of the three single-angle results."""
+def test_rotation_info_matches_oracle(reader, reader_exact, oracle_reader):
+    """rotation_info (f4) end to end: the same boxes in the same (top-y sorted) order as the oracle's batched branch.  In the default
+    bf16 mode which variant wins a box depends on confidences that differ by bf16-vs-fp32 noise with random recogniser weights (the
+    inputs of every variant are bit-exact, test_rotated_crops_bit_exact), so there the selection is checked as a property of the
+    product: the result for [90, 180, 270] is, box by box, the most confident of the three single-angle results.  The exact mode must
+    reproduce the oracle's texts and confidences outright."""
     from bb_ocr_amd import synth
 
     img = synth.page(322, width=512, height=256, lines=3, margin=24)[0]
@@ -345,8 +346,11 @@ def test_rotation_info_matches_oracle(reader, oracle_reader):
         got = reader.readtext(img, rotation_info=rot)
         want = oracle_reader.readtext(img, rotation_info=rot)
         assert [g[0] for g in got] == [[list(map(int, p)) for p in w[0]] for w in want]
-        assert all(abs(g[2] - float(w[2])) < 0.2 for g, w in zip(got, want))
         single[tuple(rot)] = got
+        # the exact recogniser mode picks the same variant as the oracle: same text, confidence to 1e-3
+        ex = reader_exact.readtext(img, rotation_info=rot)
+        assert [g[0] for g in ex] == [g[0] for g in got] and [g[1] for g in ex] == [w[1] for w in want]
+        assert all(abs(g[2] - float(w[2])) <= 1e-3 * max(float(w[2]), 1e-3) for g, w in zip(ex, want))
     for i, box in enumerate(single[(90, 180, 270)]):
         cands = [single[(90,)][i], single[(180,)][i], single[(270,)][i]]
         best = max(cands, key=lambda r: r[2])
