@@ -50,6 +50,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
     per second: a 1280x960 JPEG costs ~10 ms of one core.  The files are therefore decoded by ``decode_workers`` threads (default:
     the host's cores, at most 16; PIL releases the GIL while decoding) and a shape group is sent to the device as soon as it is
     full, so the decode of later pages overlaps the device batch of earlier ones (ctypes releases the GIL during the C call)."""
+    import collections
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -64,27 +65,62 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
         decode_workers = max(1, min(8, os.cpu_count() or 1, len(idxs)))
 
     # three overlapped stages: decode pool -> assembler thread (groups pages by shape, stacks a full group into one host batch)
-    # -> this thread (device call + result strings).  The queue holds at most two assembled batches (2 x 300 MB at 64 pages).
+    # -> this thread (device call + result strings).  Back-pressure end to end: at most `window` decoded pages exist outside the two
+    # assembled batches the queue may hold (a decode is only submitted once a slot is free, and a slot is released when its page has
+    # been copied into a batch), so the resident set is bounded by ~4 batches however many files are queued.
     batches = queue.Queue(maxsize=2)
+    window = max(2 * max_batch, 2 * decode_workers)
+    slots = threading.Semaphore(window)
+
+    def decode(i):
+        try:
+            return ocr_input_image(image_paths[i], i)
+        except Exception:
+            return None
 
     def assemble():
         try:
             by_shape = {}
+
+            def flush(group):
+                batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
+                for _ in group:
+                    slots.release()
+
             with ThreadPoolExecutor(max_workers=decode_workers) as pool:
-                futures = [(i, pool.submit(ocr_input_image, image_paths[i], i)) for i in idxs]
-                for i, fut in futures:
-                    try:
-                        rgb, gray = fut.result()
-                    except Exception:
+                pending = collections.deque()
+                it = iter(idxs)
+                done_submitting = False
+                while pending or not done_submitting:
+                    while not done_submitting and len(pending) < window and slots.acquire(blocking=not pending):
+                        i = next(it, None)
+                        if i is None:
+                            slots.release()
+                            done_submitting = True
+                            break
+                        pending.append((i, pool.submit(decode, i)))
+                    if not pending:
                         continue
+                    i, fut = pending.popleft()
+                    page = fut.result()
+                    del fut                                         # the future would keep the decoded arrays alive
+                    if page is None:
+                        slots.release()
+                        continue
+                    rgb, gray = page
                     group = by_shape.setdefault(rgb.shape, [])
                     group.append((i, rgb, gray))
                     if len(group) >= max_batch:
-                        batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
-                        by_shape[rgb.shape] = []
+                        flush(by_shape.pop(rgb.shape))
+                    elif not slots.acquire(blocking=False):
+                        # every slot is held by pages waiting in partial groups (many distinct shapes): send the largest one
+                        big = max(by_shape, key=lambda k: len(by_shape[k]))
+                        flush(by_shape.pop(big))
+                    else:
+                        slots.release()
                 for group in by_shape.values():
                     if group:
-                        batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
+                        flush(group)
         finally:
             batches.put(None)
 
@@ -98,7 +134,13 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
         try:
             res = reader.readtext_arrays(rgb, gray, **readtext_kw)
         except Exception:
-            continue
+            # the reference loses ONE page when its OCR fails (enhanced_extractor.py:529-531): retry the batch page by page
+            res = []
+            for k in range(len(ids)):
+                try:
+                    res.append(reader.readtext_arrays(rgb[k:k + 1], gray[k:k + 1], **readtext_kw)[0])
+                except Exception:
+                    res.append([])
         for i, r in zip(ids, res):
             texts[i] = " ".join(t[1] for t in r)
     worker.join()

@@ -350,20 +350,32 @@ def test_extractor_downscale_rule_and_batching(tmp_path):
     im.save(buf, format="JPEG", quality=90)
     assert np.array_equal(rgb0, np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
 
+    good = tmp_path / "good.png"
+    arr = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    arr[0, 0] = (1, 2, 3)
+    Image.fromarray(arr).save(good)
+    poison = np.asarray(Image.open(small).convert("RGB"))[0, 0].tolist()
+
     class FakeReader:
         def __init__(self):
             self.batches = []
 
         def readtext_arrays(self, rgb, gray=None, **kw):
             self.batches.append(rgb.shape)
-            if rgb.shape[1] == 300:
-                raise RuntimeError("boom")             # a failing batch maps to empty text, like :529-531
+            if any(p[0, 0].tolist() == poison for p in rgb):
+                raise RuntimeError("boom")             # a batch holding the bad page fails as a whole ...
             return [[(None, f"w{rgb.shape[2]}", 0.9), (None, "x", 0.5)] for _ in range(rgb.shape[0])]
 
     fr = FakeReader()
-    texts = eb.extract_texts(fr, [big, small, big, tmp_path / "missing.png"], [1, 2, 0, 3, 7])
-    assert texts == {1: "", 2: "w2400 x", 0: "w1600 x", 3: ""}
-    assert sorted(fr.batches) == sorted([(1, 300, 400, 3), (1, 800, 2400, 3), (1, 533, 1600, 3)])
+    texts = eb.extract_texts(fr, [big, small, big, tmp_path / "missing.png", good], [1, 2, 0, 3, 7, 4])
+    # ... and is retried page by page: only the bad page maps to empty text, like the reference's per-page except (:529-531)
+    assert texts == {1: "", 2: "w2400 x", 0: "w1600 x", 3: "", 4: "w400 x"}
+    assert sorted(fr.batches) == sorted([(2, 300, 400, 3), (1, 300, 400, 3), (1, 300, 400, 3), (1, 800, 2400, 3), (1, 533, 1600, 3)])
+    # back-pressure: many files, tiny batches -- every page still comes out once, in any order
+    many = [good] * 37
+    fr2 = FakeReader()
+    t2 = eb.extract_texts(fr2, many, max_batch=4, decode_workers=3)
+    assert t2 == {i: "w400 x" for i in range(37)} and sum(b[0] for b in fr2.batches) == 37 and max(b[0] for b in fr2.batches) <= 4
 
 
 def test_paragraph_and_ignore_mask_rules():
