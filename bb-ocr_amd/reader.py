@@ -204,7 +204,7 @@ class Reader:
     def __init__(self, lang_list, gpu=True, model_storage_directory=None, user_network_directory=None,
                  detect_network="craft", recog_network="standard", download_enabled=True, detector=True, recognizer=True,
                  verbose=True, quantize=True, cudnn_benchmark=False, weights=None, device_index=None, det_sub_batch=0,
-                 rec_max_cols=0, precision="bf16", **_ignored):
+                 rec_max_cols=0, precision=None, **_ignored):
         import torch
 
         if list(lang_list) != ["en"]:
@@ -218,6 +218,8 @@ class Reader:
         self.device = f"cuda:{self.device_index}"
         self._lib = _lib.load()
         self._lock = threading.Lock()
+        if precision is None:       # the reference constructs Reader(["en"], gpu=...) (enhanced_extractor.py:153): the mode comes from the environment
+            precision = os.environ.get("BBOCR_PRECISION", "bf16").strip().lower()
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
         self.precision = precision
