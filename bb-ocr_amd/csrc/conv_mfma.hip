@@ -793,6 +793,160 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #endif
 }
 
+// ================================================================================================ 3x3, resident weights
+// The half-resolution tail of CRAFT (upconv4.3x3 64->32, conv_cls.0/.2 32->32, conv_cls.4 32->16 + classifier tail) has <= 32 real
+// couts and 1-2 input chunks: its tiles are 9-18 short k-steps, and in conv3x3_dma_kernel every 16x16 tile re-fetches ALL of the
+// layer's weights through LDS-DMA (36-72 KB of weight slices against a 20-41 KB activation patch) behind one barrier per k-step --
+// those launches ran at the LDS-DMA fill rate, not at the HBM rate (3.5 TB/s of algorithmic bytes).  Here a PERSISTENT workgroup
+// loads the NF = 2 real cout fragments of every (chunk, tap) slice ONCE (2 KB each, 18-36 KB in all) and then walks tiles
+// tile0 + i * gridDim.x: per tile only the 18x18 activation patch is DMA'd (the next tile's while this one is multiplied when DB),
+// the k-loop reads weights and patch from LDS without a single barrier, and the shared epilogue stores.  Two barriers per tile.
+template <int EL, int NCH, bool DB>
+__global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) {
+    constexpr int MF = 4, NF = 2, NP = 324, NPB = 6, NK = NCH * 9;
+    constexpr int WSL = NF * 1024;                       // resident bytes per (chunk, tap) slice: fragments 0 and 1 of the 4 KB slice
+    constexpr int PCH = NP * 64;                         // patch bytes per chunk
+    constexpr int NBUF = DB ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wres = smem;                    // [NK][WSL]
+    unsigned char* const pbuf = smem + NK * WSL;         // [NBUF][NCH][PCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    // resident weights: NK slices x 2 KB, 4 KB per workgroup-wide DMA instruction (two slices)
+    {
+        const unsigned char* wsrc = (const unsigned char*)a.wpk;
+#pragma unroll
+        for (int k2 = 0; k2 < (NK + 1) / 2; ++k2) {
+            const int ks = k2 * 2 + (tid >> 7);          // threads 0..127 -> slice 2*k2, 128..255 -> slice 2*k2 + 1
+            if (ks < NK)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16),
+                                                 (__attribute__((address_space(3))) void*)(wres + (k2 * 2 + (wave >> 1)) * WSL + (wave & 1) * 1024), 16, 0, 0);
+        }
+    }
+    const int pw_magic = (65536 + 18 - 1) / 18;
+    auto issue_patch = [&](int tile, int buf) {
+        int id = tile;
+        const int tx = id % a.tiles_x;
+        id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int n = id / a.tiles_y;
+        const int iy0 = ty * 16 - 1, ix0 = tx * 16 - 1;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int pix = pb * 64 + lane;
+            const int py = (pix * pw_magic) >> 16, px = pix - py * 18;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = py < 18 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const size_t sp = ((size_t)(n * a.H + iy) * a.W + ix) * a.in0_cs + wave * 8;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint16_t* gp = ok ? a.in0 + sp + c * 32 : (const uint16_t*)a.zero;
+                if ((pb + 1) * 64 <= NP || pix < NP)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)(pbuf + (buf * NCH + c) * PCH + (wave * NP + pb * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    int frag_off[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) frag_off[f] = ((wm * MF + f) * 18) * 16;      // fragment F = tile row F (fpr = 1)
+    const int lane_patch_off = ((lane >> 4) * NP + (lane & 15)) * 16;
+    const int lane_w_off = lane * 16;
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);         // the tiles in flight on one XCD are neighbours: their halos meet in one L2
+    if (tile < ntiles) issue_patch(tile, 0);
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if constexpr (DB) {
+            // every wave has finished reading buffer buf^1 (tile - gridDim.x): the next tile's patch may land there
+            asm volatile("s_barrier" ::: "memory");
+            if (next < ntiles) {
+                issue_patch(next, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPB * NCH) : "memory");     // vmcnt retires in order: this tile's patch (and the weights) have landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        f32x4 acc[MF][4];
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned char* pc = pbuf + (buf * NCH + c) * PCH + lane_patch_off;
+            const bool relu = a.relu_in0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const unsigned char* wb = wres + (c * 9 + tap) * WSL + lane_w_off;
+                const unsigned char* pb = pc + ((tap / 3) * 18 + (tap % 3)) * 16;
+                typename El<EL>::v8 af[NF], bq[MF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
+                if (relu) {
+                    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(typename El<EL>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
+                }
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
+            }
+        }
+        int id = tile;
+        const int tx = id % a.tiles_x;
+        id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int n = id / a.tiles_y;
+        if constexpr (!DB) {
+            // single patch buffer: everybody is done reading it, the next tile's patch travels while this tile's epilogue stores
+            asm volatile("s_barrier" ::: "memory");
+            if (next < ntiles) issue_patch(next, 0);
+        }
+        conv_epilogue<EL, MF>(a, acc, n, 0, ty * 16, tx * 16, wm, 0, 1, lane, 64);
+        if constexpr (DB) buf ^= 1;
+    }
+}
+
+template <int EL>
+static hipError_t launch_resw(const ConvArgs& a, hipStream_t s) {
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    static const int db_knob = diag_knob("BBOCR_RESW_DB", 1);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    auto go = [&](auto kern, size_t smem, int per_cu, bool& attr) -> hipError_t {
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        const int grid = ntiles < ncu * per_cu ? ntiles : ncu * per_cu;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+        return hipGetLastError();
+    };
+    constexpr size_t P = 324 * 64, W1 = 9 * 2048, W2 = 18 * 2048;
+    static bool at[4] = {false, false, false, false};
+    if (a.nchunks == 1) {
+        if (db_knob) return go(conv3x3_resw_kernel<EL, 1, true>, W1 + 2 * P, 2, at[0]);          // 59.9 KB: two workgroups per CU
+        return go(conv3x3_resw_kernel<EL, 1, false>, W1 + P, 4, at[1]);                           // 39.2 KB: four
+    }
+    if (db_knob >= 2) return go(conv3x3_resw_kernel<EL, 2, true>, W2 + 4 * P, 1, at[2]);           // 119.8 KB: one
+    return go(conv3x3_resw_kernel<EL, 2, false>, W2 + 2 * P, 2, at[3]);                            // 78.3 KB: two
+}
+
 // ================================================================================================ 1x1, LDS-DMA staged
 // 1x1 convolutions (fc7, the U-net "concat + 1x1" layers, the LSTM input projections, the linear layers, the class
 // projection) are plain GEMMs over the flattened pixel axis: [pixels, Cin] x [Cin, Cout].  One k-step per 32-channel chunk;
@@ -1029,6 +1183,9 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
         }
         if (three && npb == 6 && a.PH * a.PW == 324) {
             static const bool half = (diag_knob("BBOCR_CONV_NF2", 1) != 0);   // A/B knob
+            static const bool resw = (diag_knob("BBOCR_CONV_RESW", 1) != 0);    // A/B knob
+            if (resw && half && a.cout_store <= 32 && a.nchunks <= 2 && a.sub == 1 && !a.C1 && !a.pool_mode && a.TH == 16 && a.TW == 16 && a.ntiles_n == 1)
+                return launch_resw<EL>(a, s);
             if (half && a.cout_store <= 32) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324>(a, grid, s);
         }

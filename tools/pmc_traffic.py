@@ -14,7 +14,7 @@ def per_layer(d, counter):
     f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getsize)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    conv = [r for r in rows if "conv3x3_dma" in r["Kernel_Name"] or "conv1x1_dma" in r["Kernel_Name"] or "conv_mfma" in r["Kernel_Name"]]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv3x3_dma", "conv1x1_dma", "conv_mfma", "conv3x3_resw"))]
     start = max(i for i, r in enumerate(conv) if "conv3x3_dma" in r["Kernel_Name"] and ", true" in r["Kernel_Name"])   # fused conv1_2 = first launch of a pass
     return [(r["Kernel_Name"][:r["Kernel_Name"].find("(")], float(r["Counter_Value"])) for r in conv[start:]]
 
