@@ -947,6 +947,212 @@ static hipError_t launch_resw(const ConvArgs& a, hipStream_t s) {
     return go(conv3x3_resw_kernel<EL, 2, false>, W2 + 2 * P, 2, at[3]);                            // 78.3 KB: two
 }
 
+// ================================================================================================ CRAFT upconv4 in one launch
+// upconv4 = [1x1 (cat[up(y), s1]) 192 -> 64 + BN + ReLU] -> [3x3 64 -> 32 + BN + ReLU] at the half-resolution grid (480 x 640 for a 1280x960
+// page).  As two launches (conv1x1_dma<ADDUP> + the resident 3x3) the 64-channel intermediate u4a makes a round trip through HBM
+// (39 MB written + 50 MB read per page) and the 1x1 moves 128 MB per page for 2.5 GFLOP.  Here the resident-weights 3x3 PRODUCES its own
+// 18x18x64 input patch in LDS, the way conv1_2 produces conv1_1: per 16 patch pixels a wave loads the s1 pixels straight into MFMA B
+// fragments (4 x 16 B per lane: 128 channels), multiplies them with the 1x1 weights held in REGISTERS (16 fragments = 64 VGPRs, loaded
+// once per persistent workgroup), adds bias and the 2x bilinear up-sampling of z (8 gathered 16-byte loads), applies ReLU, rounds to the
+// element type and writes the two 32-channel chunk slots of the pixel -- bit for bit what the 1x1 launch stored.  The loads of fragment
+// i + 1 are in flight while fragment i is multiplied and blended.  u4a never exists in HBM.
+template <int EL>
+__global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
+    constexpr int MF = 4, NF = 2, NP = 324, NK = 18, WSL = NF * 1024, PCH = NP * 64, NFRAG = 21;
+    typedef typename El<EL>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wres = smem;                    // [18][2 KB]   upconv4.conv.3, fragments 0 and 1 of every (chunk, tap) slice
+    unsigned char* const pbuf = smem + NK * WSL;         // [2 chunks][4 groups][324 px] x 16 B   u4a patch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pl = lane & 15;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    {
+        const unsigned char* wsrc = (const unsigned char*)a.wpk;
+#pragma unroll
+        for (int k2 = 0; k2 < NK / 2; ++k2) {
+            const int ks = k2 * 2 + (wave >> 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16),
+                                             (__attribute__((address_space(3))) void*)(wres + ks * WSL + (wave & 1) * 1024), 16, 0, 0);
+        }
+    }
+    // 1x1 weights: packed slice c (32 input channels) x fragment j (16 couts in the epilogue's run order) -> registers for the whole launch
+    v8 w1[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1[c][j] = *(const v8*)((const unsigned char*)a.aux_w + (size_t)c * 4096 + j * 1024 + lane * 16);
+    // bias of the 1x1 in the accumulator order of a lane (run h, position i): 16 floats per lane group, kept in LDS (registers are what
+    // this kernel is short of: 64 hold the 1x1 weights) and added after the MFMAs in the two-launch path's order ((acc + bias) + up(z))
+    float* const b1s = (float*)(pbuf + 2 * PCH);         // [4 groups][16]
+    if (tid < 64) b1s[tid] = a.aux_b[((tid & 15) >> 3) * 32 + (tid >> 4) * 8 + (tid & 7)];
+    __syncthreads();
+    const int LH = a.up_H >> 1, LW = a.up_W >> 1;
+
+    struct Geo { int pp, cy, cx; bool inside; };
+    auto geo = [&](int oy0, int ox0, int fi) {
+        Geo G;
+        G.pp = fi * 16 + pl;
+        const int ppc = G.pp < NP ? G.pp : NP - 1;
+        const int py = ppc / 18, px = ppc - py * 18;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        G.inside = G.pp < NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        G.cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);       // any valid address: masked at the store
+        G.cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+        return G;
+    };
+    // s1 pixel -> the four B fragments of the 1x1 (128 channels), straight from memory
+    auto issue_s = [&](int n, const Geo& G, v8 (&sv)[4]) {
+        const uint16_t* sp = a.in0 + ((size_t)(n * a.H + G.cy) * a.W + G.cx) * a.in0_cs + g * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sv[c] = *(const v8*)(sp + c * 32);
+    };
+    // one fragment: gather z (issued first: it has the MFMA stream to arrive), then the NEXT fragment's s1 loads, then 16 MFMAs, blend, store
+    auto produce = [&](int n, const Geo& G, const v8 (&sv)[4], bool more, const Geo& Gn, v8 (&sn)[4]) {
+        // F.interpolate(scale_factor 2, bilinear, align_corners=False) of z at (cy, cx): the arithmetic of conv_epilogue<ADDUP>
+        float sy = ((float)G.cy + 0.5f) * 0.5f - 0.5f, sx = ((float)G.cx + 0.5f) * 0.5f - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < LH - 1 ? 1 : 0), x1 = x0 + (x0 < LW - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const f32x2_t w00 = {hy * hx, hy * hx}, w01 = {hy * lx, hy * lx}, w10 = {ly * hx, ly * hx}, w11 = {ly * lx, ly * lx};
+        const uint16_t* zb = a.addup + (size_t)n * LH * LW * a.up_cs + g * 8;
+        const uint16_t* z00 = zb + ((size_t)y0 * LW + x0) * a.up_cs;
+        const uint16_t* z01 = zb + ((size_t)y0 * LW + x1) * a.up_cs;
+        const uint16_t* z10 = zb + ((size_t)y1 * LW + x0) * a.up_cs;
+        const uint16_t* z11 = zb + ((size_t)y1 * LW + x1) * a.up_cs;
+        u32x4 q[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            q[h * 4 + 0] = *(const u32x4*)(z00 + h * 32); q[h * 4 + 1] = *(const u32x4*)(z01 + h * 32);
+            q[h * 4 + 2] = *(const u32x4*)(z10 + h * 32); q[h * 4 + 3] = *(const u32x4*)(z11 + h * 32);
+        }
+        if (more) issue_s(n, Gn, sn);
+        __builtin_amdgcn_sched_barrier(0);                   // loads first (vmcnt retires in order: z of this fragment before s1 of the next)
+        f32x4 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = El<EL>::mfma(w1[c][j], sv[c], d[j]);
+        if (G.pp < NP) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 o;
+                const f32x4 bA = *(const f32x4*)(b1s + g * 16 + h * 8), bB = *(const f32x4*)(b1s + g * 16 + h * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bk0 = i < 2 ? bA[2 * i] : bB[2 * i - 4], bk1 = i < 2 ? bA[2 * i + 1] : bB[2 * i - 3];
+                    f32x2_t t = El<EL>::unpack2(q[h * 4][i]) * w00;
+                    t = __builtin_elementwise_fma(El<EL>::unpack2(q[h * 4 + 1][i]), w01, t);
+                    t = __builtin_elementwise_fma(El<EL>::unpack2(q[h * 4 + 2][i]), w10, t);
+                    t = __builtin_elementwise_fma(El<EL>::unpack2(q[h * 4 + 3][i]), w11, t);
+                    const int k = h * 8 + i * 2;             // run h, positions 2i / 2i + 1 (conv_epilogue's v index)
+                    const float x0v = fmaxf(d[k >> 2][k & 3] + bk0 + t[0], 0.f), x1v = fmaxf(d[(k + 1) >> 2][(k + 1) & 3] + bk1 + t[1], 0.f);
+                    o[i] = G.inside ? El<EL>::pack2(x0v, x1v) : 0u;      // outside the image: the 3x3's zero padding
+                }
+                *(u32x4*)(pbuf + h * PCH + (g * NP + G.pp) * 16) = o;
+            }
+        }
+    };
+    int frag_off[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) frag_off[f] = ((wave * MF + f) * 18) * 16;
+    const int lane_patch_off = (g * NP + pl) * 16;
+    const int lane_w_off = lane * 16;
+
+    for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += gridDim.x) {
+        int id = tile;
+        const int tx = id % a.tiles_x;
+        id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int n = id / a.tiles_y;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+        // ---- phase A: the patch.  Fragments wave, wave + 4, ... (21 in all); s1 loads run one fragment ahead
+        v8 sA[4], sB[4];
+        Geo G0 = geo(oy0, ox0, wave);
+        issue_s(n, G0, sA);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int fi = wave + 4 * i;
+            if (fi < NFRAG) {
+                const bool more = fi + 4 < NFRAG;
+                const Geo G1 = geo(oy0, ox0, more ? fi + 4 : fi);
+                if (i & 1) produce(n, G0, sB, more, G1, sA);
+                else produce(n, G0, sA, more, G1, sB);
+                G0 = G1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // patch complete (and, first tile, the resident weights)
+        // ---- phase B: 3x3 from LDS, no barrier inside
+        f32x4 acc[MF][4];
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned char* pc = pbuf + c * PCH + lane_patch_off;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const unsigned char* wb = wres + (c * 9 + tap) * WSL + lane_w_off;
+                const unsigned char* pb = pc + ((tap / 3) * 18 + (tap % 3)) * 16;
+                v8 af[NF], bq[MF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) af[j] = *(const v8*)(wb + j * 1024);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) bq[f] = *(const v8*)(pb + frag_off[f]);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");          // everybody is done reading the patch: the next tile's phase A may overwrite it
+        conv_epilogue<EL, MF>(a, acc, n, 0, oy0, ox0, wave, 0, 1, lane, 64);
+    }
+}
+
+template <int EL>
+static hipError_t launch_up4_el(const ConvArgs& a, hipStream_t s) {
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t smem = 18 * 2048 + 2 * 324 * 64 + 256;  // 78.6 KB: two workgroups per CU
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_up4_kernel<EL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const int grid = ntiles < 2 * ncu ? ntiles : 2 * ncu;
+    hipLaunchKernelGGL(conv3x3_up4_kernel<EL>, dim3(grid), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_up4_fused(const ConvPlan& p1, const ConvPlan& p3, ConvArgs a, hipStream_t s) {
+    static const bool on = (diag_knob("BBOCR_UP4_FUSED", 1) != 0);      // A/B knob (diagnostic builds)
+    if (!on || p1.KH != 1 || p1.Cin != 128 || p1.Cout != 64 || p1.BN != 64 || p3.KH != 3 || p3.Cin != 64 || p3.Cout_pad != 64 || p3.BN != 64 ||
+        p1.el != p3.el || p1.split || p3.split || a.in0_cs != 128 || a.up_cs != 64 || !a.addup || !a.zero || a.cout_store > 32 || (a.up_H & 1) || (a.up_W & 1) ||
+        a.up_H != a.H || a.up_W != a.W)
+        return hipErrorNotSupported;
+    a.KH = a.KW = 3; a.pad_h = a.pad_w = 1; a.dil = 1; a.sub = 1;
+    a.OH = a.H; a.OW = a.W; a.TH = a.TW = 16;
+    a.tiles_x = (a.OW + 15) / 16; a.tiles_y = (a.OH + 15) / 16; a.ntiles_n = 1; a.nchunks = 2; a.ntaps = 9;
+    a.aux_w = p1.d_w; a.aux_b = p1.d_b;
+    a.wpk = p3.d_w; a.bias = p3.d_b;
+    a.acc_scale = 1.f; a.dbg = 0;
+    if ((long long)a.N * a.tiles_x * a.tiles_y > 0x7fffffffLL) return hipErrorNotSupported;
+    return p3.el ? launch_up4_el<1>(a, s) : launch_up4_el<0>(a, s);
+}
+
 // ================================================================================================ 1x1, LDS-DMA staged
 // 1x1 convolutions (fc7, the U-net "concat + 1x1" layers, the LSTM input projections, the linear layers, the class
 // projection) are plain GEMMs over the flattened pixel axis: [pixels, Cin] x [Cin, Cout].  One k-step per 32-channel chunk;

@@ -28,6 +28,27 @@ void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a) {
     c->prof_recs.push_back(r);
 }
 
+// the fused upconv4 launch, timed like two conv launches (algorithmic FLOPs of the 1x1 over s1 and of the 3x3)
+static hipError_t launch_up4_profiled(bbocr_ctx* c, const ConvArgs& a) {
+    if (c->profiling == 0 || (c->profiling == 1 && c->prof_group != 0)) return launch_up4_fused(c->up4s, c->up4b, a, c->cur);
+    hipEvent_t e0, e1;
+    auto get_event = [&](hipEvent_t& e) {
+        if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else HIPCHK(hipEventCreate(&e));
+    };
+    get_event(e0);
+    get_event(e1);
+    HIPCHK(hipEventRecord(e0, c->cur));
+    const hipError_t r = launch_up4_fused(c->up4s, c->up4b, a, c->cur);
+    HIPCHK(hipEventRecord(e1, c->cur));
+    if (r != hipSuccess) { c->prof_pool.push_back(e0); c->prof_pool.push_back(e1); return r; }
+    bbocr_ctx::ProfRec rec;
+    rec.e0 = e0; rec.e1 = e1; rec.group = c->prof_group;
+    rec.flops = 2.0 * a.N * a.H * a.W * (128.0 * 64.0 + 64.0 * 32.0 * 9.0);
+    c->prof_recs.push_back(rec);
+    return hipSuccess;
+}
+
 // Split-fp16 plans (ConvPlan::split, exact recogniser mode): the activation `a0` is a pair tensor [hi | lo] whose Act::C counts BOTH
 // halves; the launch reads [hi | lo | hi] (in1 = the hi half again) and, unless it writes fp32, stores its output as a pair too.
 static void conv_sources(const ConvPlan& p, ConvArgs& a, const Act& a0, const Act* a1) {
@@ -144,8 +165,30 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     Act u2b = conv_act(c, c->up2b, u2a, false, nullptr, false, true, 128);
     Act u3a = up_stage(c->up3y, c->up3s, u2b, s2, false, 128);
     Act u3b = conv_act(c, c->up3b, u3a, false, nullptr, false, true, 64);
-    Act u4a = up_stage(c->up4y, c->up4s, u3b, s1, false, 64);
-    Act u4b = conv_act(c, c->up4b, u4a, false, nullptr, false, true, 32);
+    // upconv4 as ONE launch behind z = W_y u3b: the 3x3 produces its own input patch (1x1 over s1 + up(z) + ReLU) in LDS, so the
+    // 64-channel u4a never reaches HBM (conv_mfma.hip::conv3x3_up4_kernel); any other shape takes the two launches
+    Act u4b{nullptr, s1.N, s1.H, s1.W, 32};
+    {
+        Act z = conv_act(c, c->up4y, u3b, false, nullptr, false, false, 64);
+        u4b.p = c->arena.alloc<uint16_t>((size_t)s1.N * s1.H * s1.W * 32);
+        bool fused = false;
+        if (!ar.dry) {
+            ConvArgs a{};
+            a.in0 = s1.p; a.C0 = s1.C; a.in0_cs = s1.C;
+            a.N = s1.N; a.H = s1.H; a.W = s1.W;
+            a.addup = z.p; a.up_H = s1.H; a.up_W = s1.W; a.up_cs = z.C;
+            a.relu_out = 1; a.out = u4b.p; a.out_cs = 32; a.cout_store = 32;
+            a.zero = c->zero_page;
+            const hipError_t e = launch_up4_profiled(c, a);
+            if (e == hipSuccess) fused = true;
+            else if (e != hipErrorNotSupported) HIPCHK(e);
+        }
+        if (!fused) {
+            Act u4a{c->arena.alloc<uint16_t>((size_t)s1.N * s1.H * s1.W * 64), s1.N, s1.H, s1.W, 64};
+            run_conv(c, c->up4s, s1, false, nullptr, false, true, u4a.p, 64, 64, false, &z);
+            run_conv(c, c->up4b, u4a, false, nullptr, false, true, u4b.p, 32, 32, false);
+        }
+    }
     Act c1 = conv_act(c, c->cls0, u4b, false, nullptr, false, true, 32);
     Act c2 = conv_act(c, c->cls2, c1, false, nullptr, false, true, 32);
     // conv_cls.4 (3x3 32->16 + ReLU) with conv_cls.6/.8 fused into its epilogue: writes the fp32 heat-map directly

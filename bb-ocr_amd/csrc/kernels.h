@@ -41,6 +41,10 @@ struct ConvArgs {
     const float* c11_b;
     int rgb_H, rgb_W;
     unsigned long long* stamps;   // diagnostic (BBOCR_CONV_STAMPS): per workgroup {t_start, t_prologue, t_mainloop, t_end} s_memtime; null in production
+    // conv3x3_up4_kernel (CRAFT upconv4 as ONE launch): in0 = the skip tensor s1 [N,H,W,128], addup/up_* = z = W_y y at half resolution,
+    // aux_w / aux_b = the packed 1x1 weights (64 couts x 128 cin, BN = 64 plan) and bias of upconv4.conv.0; wpk / bias = upconv4.conv.3
+    const uint16_t* aux_w;
+    const float* aux_b;
     float acc_scale;       // accumulators are multiplied by this before the bias (set from ConvPlan::acc_scale by launch_conv; 1 unless
                            // the packed weights carry a power-of-two scale, see the split-fp16 plans)
     int split_off;         // > 0 (fp16 element type only): every stored value v goes out as the pair hi = fp16(v) at its channel and
@@ -64,6 +68,10 @@ size_t conv_packed_elems(const ConvPlan& p);
 // w: fp32 [Cout][Cin][KH][KW] already BN-folded; out: bf16 bits, layout [ntile][chunk][tap][frag][lane][8]
 void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out);
 hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zero must be set (device zero page)
+// upconv4 of CRAFT fused: u4b = relu(conv3x3(relu(up(z) + W_s s1 + b_s)) + b): p1 = the 1x1 plan over s1 (128 -> 64), p3 = the 3x3 plan (64 -> 32).
+// a: in0 = s1 (in0_cs = 128), addup = z (up_cs = 64), N/H/W of the full-resolution image, out/out_cs/cout_store of u4b.  Returns
+// hipErrorNotSupported when the shapes are not the ones the kernel is built for (the caller then runs the two launches).
+hipError_t launch_up4_fused(const ConvPlan& p1, const ConvPlan& p3, ConvArgs a, hipStream_t s);
 
 // ------------------------------------------------------------------ detector front/back (craft_misc.hip)
 void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/, int el);   // K = tap*4 + channel, couts in the conv epilogue's run order

@@ -12,8 +12,10 @@ start = idx[-1]
 k = 0; tot = 0.0; other = 0.0
 for r in rows[start:]:
     n = r['Kernel_Name']; d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if 'conv_mfma' in n or 'conv3x3_dma' in n or 'conv1x1_dma' in n or 'conv3x3_resw' in n:
+    if 'conv_mfma' in n or 'conv3x3_dma' in n or 'conv1x1_dma' in n or 'conv3x3_resw' in n or 'conv3x3_up4' in n:
         name, m = MACS[k]; k += 1
+        if 'conv3x3_up4' in n:          # upconv4's 1x1 over s1 and its 3x3 in one launch
+            name, m = 'up4s+b', m + MACS[k][1]; k += 1
         print(f"{name:8s} {n[n.find('<'):n.find('>')+1]:24s} {d:9.1f} us {m*npages*2/(d*1e-6)/1e3:8.1f} TFLOP/s  grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']}")
         tot += d
     else:

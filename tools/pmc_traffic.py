@@ -14,7 +14,7 @@ def per_layer(d, counter):
     f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getsize)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv3x3_dma", "conv1x1_dma", "conv_mfma", "conv3x3_resw"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv3x3_dma", "conv1x1_dma", "conv_mfma", "conv3x3_resw", "conv3x3_up4"))]
     start = max(i for i, r in enumerate(conv) if "conv3x3_dma" in r["Kernel_Name"] and ", true" in r["Kernel_Name"])   # fused conv1_2 = first launch of a pass
     return [(r["Kernel_Name"][:r["Kernel_Name"].find("(")], float(r["Counter_Value"])) for r in conv[start:]]
 
@@ -23,6 +23,8 @@ F, W = per_layer(fd, "FETCH_SIZE"), per_layer(wd, "WRITE_SIZE")
 assert len(F) == len(W), (len(F), len(W))
 names = ["conv1_2(+conv1_1)", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "fc6", "fc7", "up1a",
          "up1b", "up2y", "up2s", "up2b", "up3y", "up3s", "up3b", "up4y", "up4s", "up4b", "cls0", "cls2", "cls4(+tail)"]
+if any("conv3x3_up4" in kn for kn, _ in F):      # upconv4 fused: one launch for the 1x1 over s1 and the 3x3
+    names = names[:22] + ["up4s+up4b (fused)"] + names[24:]
 layers = []
 for i, ((kn, f), (_, w)) in enumerate(zip(F, W)):
     rd, wr = 2.0 * f * 1024 / npages, w * 1024 / npages
