@@ -31,3 +31,9 @@ def part(rs, label):
 part(step[:ccl], "detector")
 part(step[ccl:], "recogniser (after the last box extraction)")
 print(f"step span {(t1 - t0)/1e6:.2f} ms")
+
+if len(sys.argv) > 2 and sys.argv[2] == "launches":        # every conv / GEMM / LSTM launch of the recogniser part, in order
+    for r in step[ccl:]:
+        n = r['Kernel_Name']
+        if any(k in n for k in ('conv', 'lstm')):
+            print(f"   {n[:n.find('(')][:58]:58s} grid {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):7d} {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:9.1f} us")
