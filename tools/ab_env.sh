@@ -1,3 +1,5 @@
+# The BBOCR_* A/B knobs are read by DIAGNOSTIC builds only: make -C bb-ocr_amd/csrc DIAG=1 OUT=../libbbocr_diag.so, then
+#   export BBOCR_LIB_PATH=$PWD/bb-ocr_amd/libbbocr_diag.so
 # usage: tools/ab_env.sh VAR "v1 v2 ..." [reps]   -- alternate bench.py runs on ONE box with VAR set to each value
 VAR=$1; VALS=$2; REPS=${3:-3}
 for i in $(seq $REPS); do

@@ -1,6 +1,8 @@
 """A/B helper: run the detector on the same 8 synthetic pages under two environments and compare the heat-maps bit for bit.
 
-  python tools/ab_heat.py BBOCR_FUSE1=0 BBOCR_FUSE1=1
+  BBOCR_LIB_PATH=$PWD/bb-ocr_amd/libbbocr_diag.so python tools/ab_heat.py BBOCR_UP4_FUSED=0 BBOCR_UP4_FUSED=1
+
+(the knobs exist in diagnostic builds only: make -C bb-ocr_amd/csrc DIAG=1 OUT=../libbbocr_diag.so)
 """
 import os, subprocess, sys, tempfile
 import numpy as np
