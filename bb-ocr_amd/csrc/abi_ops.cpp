@@ -155,8 +155,9 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
         ctx->arena.begin(false);
         crnn_features(ctx, dev_crops, n, imgW, (uint16_t*)ctx->seq_v.p);
         std::vector<int> tiles;
-        for (int s0 = 0; s0 < n; s0 += 16) {
-            tiles.push_back(s0 * T); tiles.push_back(std::min(16, n - s0)); tiles.push_back(T); tiles.push_back(0);
+        const int ts = lstm_tile_seqs(rec_mode(ctx));
+        for (int s0 = 0; s0 < n; s0 += ts) {
+            tiles.push_back(s0 * T); tiles.push_back(std::min(ts, n - s0)); tiles.push_back(T); tiles.push_back(0);
         }
         ctx->seq_tables.ensure(tiles.size() * 4);
         HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -124,10 +124,12 @@ hipError_t launch_rowmean3_gather(const uint16_t* in, int Wc, int C, const CropD
                                   hipStream_t s);
 // BiLSTM recurrence: xproj bf16 [n,T,2048] (permuted channels, see lstm8_xproj_channel), out bf16 [n,T,512] (fwd | bwd)
 // tiles_dev: int4 per workgroup {first row, sequences (<=16), T, 0}; tensors are pooled over all buckets: [rows, C]
-// mode REC_SPLIT: xproj is FP32 [rows, 2048], out is the pair [rows, 512 hi | 512 lo], whh_pk comes from pack_lstm_whh_split and
-// acc_scale is the inverse of its power-of-two weight scale
+// mode REC_SPLIT: xproj is FP32 [rows, 2048], out is the pair [rows, 512 hi | 512 lo] with the lo half UNSCALED (fp16(h - hi): the linear
+// layer behind it is packed with lo scale 1), whh_pk comes from pack_lstm_whh_split and acc_scale is the inverse of its weight scale;
+// tiles hold up to lstm_tile_seqs(mode) sequences
 hipError_t launch_lstm(const void* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, int mode, float acc_scale,
                        hipStream_t s);
+int lstm_tile_seqs(int mode);    // sequences per LSTM workgroup (tile table entries): 16, or 32 for REC_SPLIT
 size_t lstm_whh_packed_elems();
 void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out, int el);
 size_t lstm_whh_split_packed_elems();

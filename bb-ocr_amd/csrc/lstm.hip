@@ -189,11 +189,11 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
 
 // ================================================================================================ exact mode (REC_SPLIT)
 // The same recurrence with every operand at fp32-grade precision: h (kept in fp32 registers) crosses LDS as the fp16 pair
-// hi = fp16(h), lo = fp16((h - hi) * 2048); W_hh is the pair (w_hi, w_lo) of fp16 fragments of w * 2^s; per fragment the three MFMAs
-// h_hi w_hi + h_hi w_lo (accumulator A) and h_lo w_hi (accumulator B) give  pre = (A + B / 2048) * 2^-s + x  with x the FP32 input
-// projection; gates with expf / tanhf and IEEE division, c and h in fp32; h leaves as the [hi | lo] pair the next split-fp16 GEMM
-// reads.  Same workgroup shape and fragment layout as lstm8_kernel (16 sequences x one direction, 8 waves, wave w owns units
-// [32w, 32w + 32) x 4 gates); all 128 weight fragments of a wave are re-streamed from L2 every step through a short register ring.
+// hi = fp16(h), lo = fp16(h - hi); W_hh is the pair (w_hi, w_lo) of fp16 fragments of w * 2^s; per fragment the three MFMAs
+// h_hi w_hi + h_hi w_lo + h_lo w_hi give  pre = acc * 2^-s + x  with x the FP32 input projection; gates with expf / tanhf and IEEE
+// division, c and h in fp32; h leaves as the [hi | lo] pair the next split-fp16 GEMM reads.  Fragment layout of lstm8_kernel (8 waves,
+// wave w owns units [32w, 32w + 32) x 4 gates, one direction per workgroup); all 128 weight fragments of a wave are re-streamed from L2
+// every step through a short register ring.
 size_t lstm_whh_split_packed_elems() { return 2 * lstm_whh_packed_elems(); }     // [hi image | lo image], each in pack_lstm_whh8's layout
 float pack_lstm_whh_split(const float* whh_fwd, const float* whh_bwd, uint16_t* out) {
     float mx = 0.f;
@@ -224,103 +224,174 @@ float pack_lstm_whh_split(const float* whh_fwd, const float* whh_bwd, uint16_t* 
     return ldexpf(1.f, -s);
 }
 
-#define LSTMX_RING 6      // weight fragments (hi + lo) in flight ahead of the MFMA stream
+// NG 16-sequence groups per workgroup share every streamed weight fragment pair; RING pairs (hi + lo) are in flight ahead of the MFMA
+// stream (sched_barrier keeps hipcc from sinking the loads next to their use).  Measured on the 2,200 sequences of a 64-page step
+// (T ~ 240, `tools/sb.sh x --precision exact`): NG = 1 / RING = 6 with the loads left to the compiler 6.7 ms per layer; NG = 1 with
+// RING = 8 / 10 / 12 / 14 pinned in flight 5.7 / 5.7 / 5.8 / 5.6 (spills) ms -- the ring depth is not what bounds a step (~24 us: 1 MB
+// of fragments per workgroup from L2, 192 MFMAs and ~5 us of expf / tanhf gate math per wave, one barrier); NG = 2 / RING = 5 (half
+// the streamed bytes per sequence, a single round of 198 workgroups) 8.8 ms: the doubled MFMA + gate work per workgroup costs more
+// than the halved stream saves.
+#ifndef LSTMX_NG
+#define LSTMX_NG 1
+#endif
+#ifndef LSTMX_RING
+#define LSTMX_RING (LSTMX_NG == 1 ? 8 : 5)
+#endif
+#define LSTMX_SEQS (16 * LSTMX_NG)
+// What bounds this kernel is the L2 -> CU stream of the weight fragments (1 MB per workgroup and time step), so one workgroup carries
+// TWO 16-sequence groups through every fragment pair it loads (6 MFMAs per pair): half the streamed bytes per sequence, and the 2,200
+// sequences of a 64-page step fit the 256 CUs in one round.  The lo half of h is kept UNSCALED here (fp16 keeps subnormals in
+// v_mfma_f32_16x16x32_f16 -- tools/micro/mfma_f16_denorm.hip -- and |h| <= 1 bounds its absolute error by 3e-8), so the h_lo term
+// shares the accumulator of the other two; the linear layer that reads the output pair is packed with lo scale 1 accordingly.
 __global__ void __launch_bounds__(512, 1) lstm_exact_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ whh, uint16_t* __restrict__ out,
                                                             const int4* __restrict__ tiles, float acc_scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][2][32 * 16 * 16];   // [parity][hi / lo][kgroup 32][seq 16] x 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstmx_smem[];
+    constexpr int NG = LSTMX_NG;
+    // [parity 2][hi / lo][group NG][kgroup 32][seq 16] x 16 B = NG x 32 KB
+    auto hb = [&](int par, int kind, int grp) { return lstmx_smem + (size_t)(((par * 2 + kind) * NG + grp) * 32 * 16 * 16); };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y;
     const int4 tile = tiles[blockIdx.x];
     const int row0 = tile.x, n = tile.y, T = tile.z;
     const int g = lane >> 4, u = lane & 15;
-    for (int i = tid; i < (int)sizeof(hbuf) / 16; i += 512) ((u32x4*)&hbuf[0][0][0])[i] = (u32x4){0u, 0u, 0u, 0u};
-    float c[2][4];
+    for (int i = tid; i < 2 * 2 * NG * 32 * 16; i += 512) ((u32x4*)lstmx_smem)[i] = (u32x4){0u, 0u, 0u, 0u};
+    float c[NG][2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int grp = 0; grp < NG; ++grp)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[a][r] = 0.f;
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[grp][a][r] = 0.f;
     typedef const __attribute__((address_space(1))) f16x8* gfrag_ptr;
     const size_t half_frags = lstm_whh_packed_elems_dev() / 8;
     const gfrag_ptr whi = (gfrag_ptr)((const f16x8*)whh + ((size_t)(dir * 8 + wave) * 64) * 64 + lane);
     const gfrag_ptr wlo = whi + half_frags;
     const int xch = dir * 1024 + (wave * 16 + u) * 8;
-    size_t xrow[4];
+    size_t xrow[NG][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xrow[r] = ((size_t)row0 + (size_t)(g * 4 + r < n ? g * 4 + r : n - 1) * T) * 2048 + xch;
-    const int wb_seq = tid >> 5, wb_kg = tid & 31;   // h write-back: 16 B of hi and 16 B of lo per thread
-    const float inv_lo = 1.0f / SPLIT_LO_SCALE;
+    for (int grp = 0; grp < NG; ++grp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sq = grp * 16 + g * 4 + r;
+            xrow[grp][r] = ((size_t)row0 + (size_t)(sq < n ? sq : n - 1) * T) * 2048 + xch;
+        }
+    const int wb_seq = tid >> 5, wb_kg = tid & 31;   // h write-back: per group 16 B of hi and 16 B of lo per thread
     __syncthreads();
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        f32x4 xq[4][2];       // [sequence r][group a]: pre-activations (i, f, g, o) of the lane's unit
+        f32x4 acc[NG][2][4];
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[grp][a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 x0[4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float* xp = xproj + xrow[r] + (size_t)t * 2048;
-            xq[r][0] = *(const f32x4*)(xp);
-            xq[r][1] = *(const f32x4*)(xp + 4);
+            const float* xp = xproj + xrow[0][r] + (size_t)t * 2048;
+            x0[r][0] = *(const f32x4*)(xp);
+            x0[r][1] = *(const f32x4*)(xp + 4);
         }
-        const unsigned char* hh = hbuf[cur][0] + (g * 16 + u) * 16;
-        const unsigned char* hl = hbuf[cur][1] + (g * 16 + u) * 16;
-        f32x4 accA[2][4], accB[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { accA[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         gfrag_ptr ph = whi, pl = wlo;
         asm volatile("" : "+v"(ph), "+v"(pl));          // keep the weight loads inside the time loop
         f16x8 rh[LSTMX_RING], rl[LSTMX_RING];
 #pragma unroll
         for (int i = 0; i < LSTMX_RING; ++i) { rh[i] = ph[(size_t)i * 64]; rl[i] = pl[(size_t)i * 64]; }
-        f16x8 ah, al;
+        __builtin_amdgcn_sched_barrier(0);              // hipcc otherwise sinks every load next to its use: the ring must really be in flight
+        const int loff = (g * 16 + u) * 16;
+        f16x8 ah[NG], al[NG];
 #pragma unroll
         for (int v = 0; v < 64; ++v) {
             const int kk = v >> 3, a = (v >> 2) & 1, q = v & 3;
-            if ((v & 7) == 0) { ah = *(const f16x8*)(hh + kk * 4 * 256); al = *(const f16x8*)(hl + kk * 4 * 256); }
+            if ((v & 7) == 0) {
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    ah[grp] = *(const f16x8*)(hb(cur, 0, grp) + loff + kk * 4 * 256);
+                    al[grp] = *(const f16x8*)(hb(cur, 1, grp) + loff + kk * 4 * 256);
+                }
+            }
             const f16x8 wh = rh[v % LSTMX_RING], wl = rl[v % LSTMX_RING];
             if (v + LSTMX_RING < 64) { rh[v % LSTMX_RING] = ph[(size_t)(v + LSTMX_RING) * 64]; rl[v % LSTMX_RING] = pl[(size_t)(v + LSTMX_RING) * 64]; }
-            accA[a][q] = El<1>::mfma(ah, wh, accA[a][q]);
-            accA[a][q] = El<1>::mfma(ah, wl, accA[a][q]);
-            accB[a][q] = El<1>::mfma(al, wh, accB[a][q]);
-        }
-        unsigned char* hnh = hbuf[cur ^ 1][0];
-        unsigned char* hnl = hbuf[cur ^ 1][1];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int unit = wave * 32 + a * 16 + u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                auto pre = [&](int q) { return fmaf(fmaf(accB[a][q][r], inv_lo, accA[a][q][r]), acc_scale, xq[r][a][q]); };
-                const float gi = 1.0f / (1.0f + expf(-pre(0)));
-                const float gf = 1.0f / (1.0f + expf(-pre(1)));
-                const float gg = tanhf(pre(2));
-                const float go = 1.0f / (1.0f + expf(-pre(3)));
-                const float cn = gf * c[a][r] + gi * gg;
-                c[a][r] = cn;
-                const float hv = go * tanhf(cn);
-                const unsigned short hi = El<1>::from_f32(hv);
-                const unsigned short lo = El<1>::from_f32((hv - El<1>::to_f32(hi)) * SPLIT_LO_SCALE);
-                const int off = ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2;
-                *(unsigned short*)(hnh + off) = hi;
-                *(unsigned short*)(hnl + off) = lo;
+            for (int grp = 0; grp < NG; ++grp) {
+                acc[grp][a][q] = El<1>::mfma(ah[grp], wh, acc[grp][a][q]);
+                acc[grp][a][q] = El<1>::mfma(ah[grp], wl, acc[grp][a][q]);
+                acc[grp][a][q] = El<1>::mfma(al[grp], wh, acc[grp][a][q]);
             }
         }
+        // gate math, group by group: group 0's input projection was requested before the MFMA stream, group 1's travels while group 0's
+        // transcendentals run (64 more live registers would not fit next to the accumulators of both groups)
+        auto load_x = [&](int grp, f32x4 (&xv)[4][2]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* xp = xproj + xrow[grp][r] + (size_t)t * 2048;     // FP32 (i, f, g, o) of the lane's two units for this (sequence, step)
+                xv[r][0] = *(const f32x4*)(xp);
+                xv[r][1] = *(const f32x4*)(xp + 4);
+            }
+        };
+        auto gates = [&](int grp, const f32x4 (&xv)[4][2]) {
+            unsigned char* hnh = hb(cur ^ 1, 0, grp);
+            unsigned char* hnl = hb(cur ^ 1, 1, grp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int unit = wave * 32 + a * 16 + u;
+                    auto pre = [&](int q) { return fmaf(acc[grp][a][q][r], acc_scale, xv[r][a][q]); };
+                    const float gi = 1.0f / (1.0f + expf(-pre(0)));
+                    const float gf = 1.0f / (1.0f + expf(-pre(1)));
+                    const float gg = tanhf(pre(2));
+                    const float go = 1.0f / (1.0f + expf(-pre(3)));
+                    const float cn = gf * c[grp][a][r] + gi * gg;
+                    c[grp][a][r] = cn;
+                    const float hv = go * tanhf(cn);
+                    const unsigned short hi = El<1>::from_f32(hv);
+                    const unsigned short lo = El<1>::from_f32(hv - El<1>::to_f32(hi));
+                    const int off = ((unit >> 3) * 16 + g * 4 + r) * 16 + (unit & 7) * 2;
+                    *(unsigned short*)(hnh + off) = hi;
+                    *(unsigned short*)(hnl + off) = lo;
+                }
+        };
+        if constexpr (NG == 2) {
+            f32x4 x1[4][2];
+            load_x(NG - 1, x1);
+            __builtin_amdgcn_sched_barrier(0);
+            gates(0, x0);
+            gates(NG - 1, x1);
+        } else {
+            gates(0, x0);
+        }
         __syncthreads();
-        if (wb_seq < n) {
-            const size_t orow = ((size_t)row0 + (size_t)wb_seq * T + t) * 1024 + dir * 256 + wb_kg * 8;
-            *(u32x4*)(out + orow) = *(const u32x4*)(hnh + (wb_kg * 16 + wb_seq) * 16);
-            *(u32x4*)(out + orow + 512) = *(const u32x4*)(hnl + (wb_kg * 16 + wb_seq) * 16);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const int sq = grp * 16 + wb_seq;
+            if (sq < n) {
+                const size_t orow = ((size_t)row0 + (size_t)sq * T + t) * 1024 + dir * 256 + wb_kg * 8;
+                *(u32x4*)(out + orow) = *(const u32x4*)(hb(cur ^ 1, 0, grp) + (wb_kg * 16 + wb_seq) * 16);
+                *(u32x4*)(out + orow + 512) = *(const u32x4*)(hb(cur ^ 1, 1, grp) + (wb_kg * 16 + wb_seq) * 16);
+            }
         }
         cur ^= 1;
     }
 }
+int lstm_tile_seqs(int mode) { return mode == REC_SPLIT ? LSTMX_SEQS : 16; }
 
 hipError_t launch_lstm(const void* xproj, const uint16_t* whh_pk, uint16_t* out, const int* tiles_dev, int ntiles, int mode, float acc_scale,
                        hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     if (mode == REC_SPLIT) {
-        hipLaunchKernelGGL(lstm_exact_kernel, dim3(ntiles, 2), dim3(512), 0, s, (const float*)xproj, whh_pk, out, (const int4*)tiles_dev, acc_scale);
+        const size_t smemx = (size_t)2 * 2 * LSTMX_NG * 32 * 16 * 16;
+        static bool attrx = false;
+        if (!attrx) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemx);
+            if (e != hipSuccess) return e;
+            attrx = true;
+        }
+        hipLaunchKernelGGL(lstm_exact_kernel, dim3(ntiles, 2), dim3(512), smemx, s, (const float*)xproj, whh_pk, out, (const int4*)tiles_dev, acc_scale);
         return hipGetLastError();
     }
     const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;

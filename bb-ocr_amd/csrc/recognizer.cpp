@@ -196,11 +196,11 @@ static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, con
     }
 }
 
-static void rec_add_tables(RecRun& run, const RecPart& part) {
+static void rec_add_tables(RecRun& run, const RecPart& part, int tile_seqs) {
     for (const RecChunk& ch : part.chunks) {
-        for (int s0 = 0; s0 < ch.n; s0 += 16) {
+        for (int s0 = 0; s0 < ch.n; s0 += tile_seqs) {
             run.tiles.push_back((int)(ch.row0 + (size_t)s0 * ch.T));
-            run.tiles.push_back(std::min(16, ch.n - s0));
+            run.tiles.push_back(std::min(tile_seqs, ch.n - s0));
             run.tiles.push_back(ch.T);
             run.tiles.push_back(0);
         }
@@ -305,7 +305,7 @@ static void recognise_pass(bbocr_ctx* c, const uint8_t* gray, int H, int W, std:
         rec_launch_part(c, gray, H, W, part, c->crop_desc, stage_a);
         c->times[3] += (float)ms_since(t0);
         RecRun run;
-        rec_add_tables(run, part);
+        rec_add_tables(run, part, lstm_tile_seqs(rec_mode(c)));
         rec_finish(c, run, texts, confs);
     }
 }
@@ -486,13 +486,13 @@ void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, cons
         RecPart part2;
         rec_plan_part(jobs, rest, (int)n_early, early->part.rows, part2);
         RecRun run;
-        rec_add_tables(run, early->part);
+        rec_add_tables(run, early->part, lstm_tile_seqs(rec_mode(c)));
         if (early->part.rows + part2.rows <= rec_max_rows(c)) {
             c->seq_v.ensure_keep(align_up(early->part.rows + part2.rows, 256) * 256 * 2 * rec_mul(c), early->part.rows * 256 * 2 * rec_mul(c));
             auto t0 = clk::now();
             rec_launch_part(c, gray, H, W, part2, c->crop_desc2, true);
             c->times[3] += (float)ms_since(t0);
-            rec_add_tables(run, part2);
+            rec_add_tables(run, part2, lstm_tile_seqs(rec_mode(c)));
             rec_finish(c, run, texts, confs);
         } else {                                   // the rest does not fit the same sequence pass: finish part 1, then the rest on its own
             rec_finish(c, run, texts, confs);

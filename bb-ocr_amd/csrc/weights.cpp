@@ -50,7 +50,7 @@ void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const s
 // scaled by a power of two so that their largest magnitude sits in [512, 1024): w_lo = fp16(w 2^s - w_hi) then stays in fp16's
 // normal range for every weight that matters; the epilogue multiplies the accumulators by 2^-s (exact).
 static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int KH, int KW, int pad, const std::vector<float>& w,
-                              const std::vector<float>& b) {
+                              const std::vector<float>& b, float lo_scale = SPLIT_LO_SCALE) {    // lo_scale: what the producer multiplied its lo half by
     if (Cin % 32) fail(BBOCR_ERR_INTERNAL, "split plan: Cin must be a multiple of 32");
     const int taps = KH * KW;
     float mx = 0.f;
@@ -68,7 +68,7 @@ static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int 
                 const float lo = f16_to_f32_host(f32_to_f16_host(v - hi));
                 float* row = w3.data() + (size_t)o * 3 * Cin * taps;
                 row[((size_t)i) * taps + t] = hi;
-                row[((size_t)Cin + i) * taps + t] = hi * (1.f / SPLIT_LO_SCALE);     // the lo activations are stored x 2048
+                row[((size_t)Cin + i) * taps + t] = hi * (1.f / lo_scale);            // the lo activations are stored x lo_scale (2048; 1 behind the LSTM)
                 row[((size_t)2 * Cin + i) * taps + t] = lo;
             }
     p = make_plan(3 * Cin, Cout, KH, KW, pad, 1, 1);
@@ -281,7 +281,7 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         std::vector<float> lw(tm.get(sm + "linear.weight", (size_t)256 * 512), tm.get(sm + "linear.weight", (size_t)256 * 512) + 256 * 512);
         std::vector<float> lb(tm.get(sm + "linear.bias", 256), tm.get(sm + "linear.bias", 256) + 256);
         if (rec_split(c)) {
-            upload_split_plan(c, c->lin[l], 512, 256, 1, 1, 0, lw, lb);
+            upload_split_plan(c, c->lin[l], 512, 256, 1, 1, 0, lw, lb, 1.f);     // reads lstm_exact_kernel's pair: lo = fp16(h - hi), unscaled
         } else {
             c->lin[l] = make_plan(512, 256, 1, 1, 0, 1, rec_el(c));
             upload_plan(c, c->lin[l], lw, lb);
