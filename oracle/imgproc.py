@@ -5,7 +5,8 @@ detector.  Upstream modules followed (easyocr==1.7.2, un-vendored, see
 oracle/__init__.py): ``easyocr/utils.py::reformat_input``,
 ``easyocr/imgproc.py::{loadImage,resize_aspect_ratio,normalizeMeanVariance}``;
 OpenCV 4.10 ``imgproc/src/resize.cpp`` (8-bit bilinear, fixed point) and
-``color_yuv.simd.hpp`` (RGB->gray).  PARITY UNPINNED (no cv2 in this image).
+``color_rgb.simd.hpp`` (RGB->gray: the 15-bit formula, PINNED by the reference's pre-processing vectors, see
+oracle/__init__.py).  The resize / normalisation steps stay PARITY UNPINNED (no cv2 in this image).
 """
 from __future__ import annotations
 
