@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline after one warm-up page (0 = skip)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
+    ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 renders every rank's pages and scatters them (dist.scatter_pages: grouped "
+                                                           "RCCL sends over xGMI) instead of every rank rendering its own shard; outside the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
     cw, ch, cb, cl, cpitch, cprec, workload = CONFIGS[args.config]
@@ -88,8 +90,18 @@ def main():
     if rank == 0:
         cs, rs = weights.designed_craft_state(0), weights.synthetic_crnn_state(0)
     mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
+    weights_path = "local (single process)"
     if world > 1:
-        reader = bdist.broadcast_packed(lambda: mk((cs, rs)), lambda: mk("empty"), src=0, via_host=(args.backend != "nccl"))
+        try:
+            t_b = time.perf_counter()
+            reader = bdist.broadcast_packed(lambda: mk((cs, rs)), lambda: mk("empty"), src=0, via_host=(args.backend != "nccl"))
+            weights_path = (f"packed device blob ({reader.weights_blob_size() / 1e6:.1f} MB) broadcast from rank 0 over "
+                            f"{'RCCL, device to device' if args.backend == 'nccl' else args.backend + ' (host hop: rehearsal only)'} "
+                            f"in {(time.perf_counter() - t_b) * 1e3:.0f} ms incl. packing")
+        except Exception as e:      # a measurement must not die on the one-off setup collective: the weights are seeded, every rank can build them
+            print(f"[bench rank {rank}] packed weight broadcast failed ({type(e).__name__}: {e}); building the seeded weights locally", file=sys.stderr, flush=True)
+            reader = mk((weights.designed_craft_state(0), weights.synthetic_crnn_state(0)))
+            weights_path = f"local on every rank (broadcast failed: {type(e).__name__})"
     else:
         reader = mk((cs, rs))
 
@@ -100,9 +112,30 @@ def main():
     page_kw = dict(width=args.width, height=args.height, lines=args.lines, line_pitch=cpitch, margin=24)
     if args.config == "a4":
         page_kw.update(font_size=20, word_gap=14, margin=60)
-    uniq = [synth.page(1234 + (g0 + i), colour=bool((g0 + i) & 1), **page_kw)[0] for i in range(min(args.unique, B))]
-    host = np.stack([uniq[i % len(uniq)] for i in range(g1 - g0)])
-    rgb = torch.from_numpy(host).cuda()
+    render = lambda a, n: [synth.page(1234 + (a + i), colour=bool((a + i) & 1), **page_kw)[0] for i in range(min(args.unique, n))]
+    pages_path = "every rank renders its own shard (no scatter)"
+    if args.scatter and world > 1:
+        # BASELINE.json configs[3] names an image scatter: the loader rank holds all pages and sends every rank its block
+        allp = None
+        if rank == 0:
+            blocks = []
+            for r in range(world):
+                ra, rb = bdist.shard_range(B * world, r, world)
+                u = render(ra, rb - ra)
+                blocks.append(np.stack([u[i % len(u)] for i in range(rb - ra)]))
+            allp = torch.from_numpy(np.concatenate(blocks))
+            if args.backend == "nccl":
+                allp = allp.cuda()
+        t_s = time.perf_counter()
+        rgb = bdist.scatter_pages(allp, B * world, (args.height, args.width, 3), src=0, device=("cuda" if args.backend == "nccl" else "cpu")).cuda()
+        torch.cuda.synchronize()
+        pages_path = f"scattered from rank 0 (dist.scatter_pages, {rgb.numel() / 1e6:.0f} MB per rank) in {(time.perf_counter() - t_s) * 1e3:.0f} ms"
+        uniq = [rgb[i].cpu().numpy() for i in range(min(args.unique, g1 - g0))]
+        del allp
+    else:
+        uniq = render(g0, B)
+        host = np.stack([uniq[i % len(uniq)] for i in range(g1 - g0)])
+        rgb = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
 
     def log(msg):
@@ -168,6 +201,7 @@ def main():
             "precision": args.precision,
             "batch_per_gpu": B, "page_wh": [args.width, args.height], "text_lines_per_page": args.lines,
             "boxes_per_step_rank0": n_boxes, "chars_per_step_rank0": n_chars, "parallelism": f"dp{world} (page shards, no data-path collective)",
+            "weights": weights_path, "pages": pages_path,
         },
         "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stage.items()},
     }

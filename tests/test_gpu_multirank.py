@@ -12,11 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_one_card():
+@pytest.mark.parametrize("scatter", [False, True])
+def test_bench_two_ranks_one_card(scatter):
+    """Both N > 1 set-ups of bench.py: the packed weight blob exported by rank 0, broadcast and imported by rank 1 (the RCCL path's
+    code, collectives over gloo with a host hop on this one-card box), every rank rendering its shard or -- ``--scatter`` -- rank 0
+    rendering all pages and dist.scatter_pages sending rank 1 its block."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-           "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo", "--batch", "8",
-           "--cpu-pages", "0"]
+           str(29537 + int(scatter)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo", "--batch", "8",
+           "--cpu-pages", "0"] + (["--scatter"] if scatter else [])
     # a child process, never an exec: this pytest process has initialised the GPU
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
@@ -26,3 +30,6 @@ def test_bench_two_ranks_one_card():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 1
     assert d["config"]["batch_per_gpu"] == 8 and "cpu_baseline" not in d          # the CPU leg runs at N = 1 only
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["weights"].startswith("packed device blob") and "MB" in d["config"]["weights"]       # not the local fallback
+    assert d["config"]["pages"].startswith("scattered from rank 0" if scatter else "every rank renders")
+    assert d["config"]["boxes_per_step_rank0"] > 100
