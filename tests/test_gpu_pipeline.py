@@ -588,3 +588,27 @@ def test_random_batches_match_single_pages(reader):
         idx = sorted(set(rng.integers(0, B, size=min(B, 5)).tolist()) | {0, B - 1})
         for i in idx:
             assert reader.readtext_device(rgb[i:i + 1])[0] == got[i], (case, B, W, H, i)
+
+
+def test_boxes_property_random_blob_maps(reader):
+    """Property test (hypothesis) of the whole box stage on the device -- threshold, CCL, statistics, row extremes, host geometry,
+    grouping -- against the oracle on the SAME maps: rotated boxes / ellipses, slivers, border contact, overlaps, link bridges, ragged
+    map sizes.  Polygons, horizontal boxes and free boxes must be identical, in order."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    from oracle import boxes as obox
+    from test_host_properties_cpu import _blob_maps
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(maps=_blob_maps(), ratio=st.sampled_from([1.0, 0.7306]), low_text=st.sampled_from([0.4, 0.2]), min_size=st.sampled_from([20, 3]))
+    def check(maps, ratio, low_text, min_size):
+        text, link = maps
+        heat = torch.from_numpy(np.stack([text, link], -1)[None].astype(np.float32)).cuda()
+        hori, free, polys = reader.boxes_from_heatmap(heat, ratio, low_text=low_text, min_size=min_size)
+        oh, of, op = obox.detect_from_heatmap(text, link, ratio, low_text=low_text, min_size=min_size)
+        assert polys[0] == [list(map(int, p)) for p in op]
+        assert hori[0] == [list(map(int, b)) for b in oh]
+        assert np.allclose(np.array(free[0], dtype=np.float64).reshape(-1, 4, 2), np.array(of, dtype=np.float64).reshape(-1, 4, 2), rtol=0, atol=1e-9)
+
+    check()
