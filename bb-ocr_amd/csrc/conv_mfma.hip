@@ -665,20 +665,25 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         const uint8_t* rgb = (const uint8_t*)a.in0;
         const float m0 = 0.485f * 255.0f, m1 = 0.456f * 255.0f, m2 = 0.406f * 255.0f;
         const float s0 = 0.229f * 255.0f, s1 = 0.224f * 255.0f, s2 = 0.225f * 255.0f;
-        for (int p = tid; p < 400; p += NT) {
+        // Every global load of the prologue is ISSUED before the first one is consumed (the page bytes of both pixels a thread owns, the
+        // conv1_1 fragments, the bias): one round trip instead of four dependent ones -- the per-tile timeline showed this prologue at
+        // 13.7 k cycles against 9.9 k for the 18 k-steps it feeds, on a kernel whose workgroups are latency-bound.
+        static_assert(NT == 256, "two patch pixels per thread");
+        int pq[2];
+        bool on_canvas[2];
+        unsigned int cr[2], cg[2], cb[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int p = tid + it * NT;
             const int py = p / 20, px = p - py * 20;
             const int iy = cur.oy0 - 2 + py, ix = cur.ox0 - 2 + px;
-            u32x2 v = {0u, 0u};
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                float r = 0.f, g = 0.f, b = 0.f;
-                if (iy < a.rgb_H && ix < a.rgb_W) {
-                    const uint8_t* q = rgb + ((size_t)(cur.n * a.rgb_H + iy) * a.rgb_W + ix) * 3;
-                    r = (float)q[0]; g = (float)q[1]; b = (float)q[2];
-                }
-                v[0] = El<EL>::pack2((r - m0) / s0, (g - m1) / s1);
-                v[1] = El<EL>::pack2((b - m2) / s2, 0.f);
-            }
-            rgbp[p] = v;
+            pq[it] = p;
+            on_canvas[it] = p < 400 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool on_page = on_canvas[it] && iy < a.rgb_H && ix < a.rgb_W;
+            // off the page: any valid address (pixel 0 of the image), the value is replaced by the canvas' raw zero below
+            const uint8_t* q = rgb + (on_page ? ((size_t)(cur.n * a.rgb_H + iy) * a.rgb_W + ix) * 3 : (size_t)cur.n * a.rgb_H * a.rgb_W * 3);
+            cr[it] = q[0]; cg[it] = q[1]; cb[it] = q[2];
+            if (!on_page) { cr[it] = 0u; cg[it] = 0u; cb[it] = 0u; }
         }
         // conv1_1 weights as MFMA A fragments: K = tap*4 + channel padded to 64 (two k-steps), couts in the run order of the
         // epilogue mapping, so that a lane's 16 outputs are exactly one 16-byte slot of each 32-channel chunk of the patch image
@@ -690,40 +695,82 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         const int g = lane >> 4, pl = lane & 15;
         float b1[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) b1[i] = a.c11_b[(i >> 3) * 32 + g * 8 + (i & 7)];
-        __syncthreads();
-        // (2) 21 fragments of 16 patch pixels (18 x 18 = 324 = 20*16 + 4), dealt round-robin to the four waves
-        for (int fi = wave; fi < 21; fi += NW) {
-            const int pp = fi * 16 + pl;
-            const int py = pp / 18, px = pp - py * 18;           // patch pixel -> its 3x3 window starts at (py, px) of the RGB patch
-            f32x4 d[4];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks1 = 0; ks1 < 2; ++ks1) {
-                int t0 = ks1 * 8 + 2 * g, t1 = t0 + 1;
-                t0 = t0 > 8 ? 8 : t0;                            // taps >= 9 meet zero weights; any valid address will do
-                t1 = t1 > 8 ? 8 : t1;
-                const int pc = pp < 324 ? py * 20 + px : 0;
-                const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
-                const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
-                const typename El<EL>::v8 bfr = __builtin_bit_cast(typename El<EL>::v8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = El<EL>::mfma(w1[ks1][j], bfr, d[j]);
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f32x4 bv = *(const f32x4*)(a.c11_b + h * 32 + g * 8 + q4 * 4);
+                b1[h * 8 + q4 * 4 + 0] = bv[0]; b1[h * 8 + q4 * 4 + 1] = bv[1]; b1[h * 8 + q4 * 4 + 2] = bv[2]; b1[h * 8 + q4 * 4 + 3] = bv[3];
             }
-            const int iy = cur.oy0 - 1 + py, ix = cur.ox0 - 1 + px;
-            const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;     // else: conv1_2's own zero padding
-            if (pp < 324) {
+        __builtin_amdgcn_sched_barrier(0);              // loads above, their consumers below
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x4 o;
+        for (int it = 0; it < 2; ++it) {
+            if (pq[it] < 400) {
+                u32x2 v = {0u, 0u};
+                if (on_canvas[it]) {
+                    v[0] = El<EL>::pack2(((float)cr[it] - m0) / s0, ((float)cg[it] - m1) / s1);
+                    v[1] = El<EL>::pack2(((float)cb[it] - m2) / s2, 0.f);
+                }
+                rgbp[pq[it]] = v;
+            }
+        }
+        __syncthreads();
+        // (2) 21 fragments of 16 patch pixels (18 x 18 = 324 = 20*16 + 4), dealt round-robin to the four waves.  A fragment is a
+        //     latency chain (LDS reads -> 8 MFMAs -> bias / ReLU / pack -> LDS write, ~1,300 cycles on its own -- the tile timeline
+        //     showed 7.8 k cycles for the 5-6 fragments of a wave); the fragments of a wave are independent, so they run as TWO
+        //     interleaved batches of three: all B operands of a batch are read first, then its 24 MFMAs, then the three epilogues.
+        auto frag_geo = [&](int fi, int& pp, int& py, int& px) {
+            pp = fi * 16 + pl;
+            py = pp / 18;
+            px = pp - py * 18;                                   // patch pixel -> its 3x3 window starts at (py, px) of the RGB patch
+        };
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = h * 8 + i * 2;
-                        const float x0 = fmaxf(d[k >> 2][k & 3] + b1[k], 0.f), x1 = fmaxf(d[(k + 1) >> 2][(k + 1) & 3] + b1[k + 1], 0.f);
-                        o[i] = inside ? El<EL>::pack2(x0, x1) : 0u;
+        for (int b3 = 0; b3 < 2; ++b3) {
+            typename El<EL>::v8 bfr[3][2];
+            int pps[3], pys[3], pxs[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int fi = wave + (b3 * 3 + q) * NW;         // fi >= 21: nothing is stored, the operands only need valid addresses
+                frag_geo(fi < 21 ? fi : 20, pps[q], pys[q], pxs[q]);
+                const int pc = pps[q] < 324 ? pys[q] * 20 + pxs[q] : 0;
+#pragma unroll
+                for (int ks1 = 0; ks1 < 2; ++ks1) {
+                    int t0 = ks1 * 8 + 2 * g, t1 = t0 + 1;
+                    t0 = t0 > 8 ? 8 : t0;                        // taps >= 9 meet zero weights; any valid address will do
+                    t1 = t1 > 8 ? 8 : t1;
+                    const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
+                    const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
+                    bfr[q][ks1] = __builtin_bit_cast(typename El<EL>::v8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+                }
+            }
+            f32x4 d[3][4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks1 = 0; ks1 < 2; ++ks1)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[q][j] = El<EL>::mfma(w1[ks1][j], bfr[q][ks1], d[q][j]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int fi = wave + (b3 * 3 + q) * NW;
+                const int pp = pps[q];
+                const int iy = cur.oy0 - 1 + pys[q], ix = cur.ox0 - 1 + pxs[q];
+                const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;     // else: conv1_2's own zero padding
+                if (fi < 21 && pp < 324) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = h * 8 + i * 2;
+                            const float x0 = fmaxf(d[q][k >> 2][k & 3] + b1[k], 0.f), x1 = fmaxf(d[q][(k + 1) >> 2][(k + 1) & 3] + b1[k + 1], 0.f);
+                            o[i] = inside ? El<EL>::pack2(x0, x1) : 0u;
+                        }
+                        *(u32x4*)(pbuf + h * patch_bytes + (g * NP + pp) * 16) = o;
                     }
-                    *(u32x4*)(pbuf + h * patch_bytes + (g * NP + pp) * 16) = o;
                 }
             }
         }
