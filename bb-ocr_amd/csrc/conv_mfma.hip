@@ -809,11 +809,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         for (int j = 0; j < NF; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
 #pragma unroll
         for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
-        if ((c * 32 < a.C0) ? a.relu_in0 : a.relu_in1) {
-            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int f = 0; f < MF; ++f) bq[f] = __builtin_bit_cast(typename El<EL>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bq[f]), z));
-        }
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
@@ -821,7 +816,23 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
+    // ReLU-on-load (the input is a BatchNorm-terminated VGG slice, conv3_3 / conv4_3): applied ONCE per chunk, in place in the LDS patch,
+    // when the chunk begins (its DMA has landed by the previous k-step's barrier) -- 6 x (ds_read, 4 integer max, ds_write) per thread and
+    // chunk.  Applied to the B fragments of every tap instead it was 32 extra VALU instructions per k-step on top of ~50, in a loop whose
+    // SIMD issue port is ~90 % busy: conv3_3 / conv4_3 ran 9 % below their un-ReLU'd twins (PMC instruction counts).
+    auto relu_patch = [&](int c) {
+        if (!((c * 32 < a.C0) ? a.relu_in0 : a.relu_in1)) return;        // wave-uniform
+        const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        s16x8* pp = (s16x8*)(pbuf + par * patch_bytes);
+#pragma unroll
+        for (int i = 0; i < (NP * 4 + NT - 1) / NT; ++i) {
+            const int k = tid + i * NT;
+            if ((i + 1) * NT <= NP * 4 || k < NP * 4) pp[k] = __builtin_elementwise_max(pp[k], z);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     auto chunk = [&](auto more_c, int c) {
+        relu_patch(c);
         [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, 9>{});
         par ^= 1;
     };
