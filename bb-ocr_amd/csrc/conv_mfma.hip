@@ -1218,27 +1218,29 @@ hipError_t launch_up4_fused(const ConvPlan& p1, const ConvPlan& p3, ConvArgs a, 
 // gathers channel group w of 256 consecutive pixels, 16 B per lane), and the barrier waits with the constant counted
 // vmcnt((RING-2) * DMAs-per-k-step).  No halo, so the tile is simply 256 consecutive pixels of N*H*W.
 template <int EL, int WM, int WN, int MF, int RING, bool ADDUP>
-__global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) conv1x1_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
-    static_assert(NW == 4, "one wave per 8-channel group of the activation tile");
+    static_assert(NW == 4 || NW == 8, "wave w gathers channel group w & 3 of the activation tile (8 waves: half of the pixel blocks each)");
     constexpr int WBUF = BN * 64, WPIECES = WBUF / 16, WPT = WPIECES / NT;
     constexpr int NPX = WM * MF * 16, NPB = NPX / 64, PBUF = NPX * 64, SLOT = WBUF + PBUF;
-    static_assert(WPIECES % NT == 0 && NPX % 64 == 0 && RING >= 3, "uniform DMA issue");
+    constexpr int PBW = NPB / (NW / 4);            // activation blocks (64 pixels x 8 channels) a wave gathers per k-step
+    static_assert(WPIECES % NT == 0 && NPX % 64 == 0 && NPB % (NW / 4) == 0 && RING >= 3, "uniform DMA issue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [RING][weights WBUF | activations PBUF]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int kg = wave & 3, pb0 = (wave >> 2) * PBW;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % a.ntiles_n;
     const int tile = bid / a.ntiles_n;
     const int px0 = tile * NPX;                // first pixel of the tile in the flattened N*H*W axis (a.OW = total pixels)
     const int nk = a.nchunks;
-    int pix[NPB];
+    int pix[PBW];
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-        const int p = px0 + pb * 64 + lane;
-        pix[pb] = p < a.OW ? p : -1;
+    for (int i = 0; i < PBW; ++i) {
+        const int p = px0 + (pb0 + i) * 64 + lane;
+        pix[i] = p < a.OW ? p : -1;
     }
     const unsigned char* wsrc = (const unsigned char*)a.wpk + (size_t)nt * nk * WBUF;
     auto issue = [&](int ks, int slot) {
@@ -1251,12 +1253,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const Conv
         const bool s0 = c < a.C0;
         const uint16_t* src = s0 ? a.in0 : a.in1;
         const int cs = s0 ? a.in0_cs : a.in1_cs;
-        const int cb = (s0 ? c : c - a.C0) + wave * 8;
+        const int cb = (s0 ? c : c - a.C0) + kg * 8;
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-            const uint16_t* g = pix[pb] >= 0 ? src + (size_t)pix[pb] * cs + cb : (const uint16_t*)a.zero;
+        for (int i = 0; i < PBW; ++i) {
+            const uint16_t* g = pix[i] >= 0 ? src + (size_t)pix[i] * cs + cb : (const uint16_t*)a.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(sb + WBUF + (wave * NPX + pb * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + WBUF + (kg * NPX + (pb0 + i) * 64) * 16), 16, 0, 0);
         }
     };
     const int lane_p_off = WBUF + ((lane >> 4) * NPX + (lane & 15)) * 16 + wm * MF * 256;
@@ -1294,7 +1296,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv1x1_dma_kernel(const Conv
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
         // k-step ks+1 was issued RING-2 k-steps ago; while the pipeline is full exactly RING-2 later issues follow it
-        if (ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 2) * (WPT + NPB)) : "memory");
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 2) * (WPT + PBW)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         slot = slot + 1 == RING ? 0 : slot + 1;
     }
@@ -1326,6 +1328,7 @@ static hipError_t launch_dma1x1(ConvArgs a, hipStream_t s) {
     const long long grid = (long long)a.tiles_x * a.ntiles_n;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     // the epilogue that adds an up-sampled tensor is its own instantiation: its register needs must not leak into the others
+    // (8-wave tiles, one workgroup per CU: a ring of 4 measured no faster than 3 -- 389 vs 383 us on fc7)
     return a.addup ? launch_dma1x1_k<EL, WM, WN, MF, true>(a, grid, s) : launch_dma1x1_k<EL, WM, WN, MF, false>(a, grid, s);
 }
 
@@ -1548,7 +1551,7 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
                      a.cout_store == p.Cout_pad))
         return hipErrorInvalidValue;
     if (conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
-        return BN == 128 ? launch_dma1x1<EL, 2, 2, 8>(a, s) : launch_dma1x1<EL, 4, 1, 4>(a, s);
+        return BN == 256 ? launch_dma1x1<EL, 2, 4, 8>(a, s) : (BN == 128 ? launch_dma1x1<EL, 2, 2, 8>(a, s) : launch_dma1x1<EL, 4, 1, 4>(a, s));
     if (conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
         const int npb = cdiv(a.PH * a.PW, 64);
         if (npb == 6 || npb == 7) {

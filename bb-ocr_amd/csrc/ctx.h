@@ -262,7 +262,7 @@ template <typename T> inline T* upload(bbocr_ctx* c, const std::vector<T>& v) {
     return (T*)d;
 }
 
-ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el = 0);
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el = 0, int bn = 0);
 void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const std::vector<float>& b);
 void free_weights(bbocr_ctx* c);
 size_t weights_blob_bytes(const bbocr_ctx* c);

@@ -25,12 +25,12 @@ static void fold_conv(const TensorMap& tm, const std::string& conv, const std::s
     }
 }
 
-ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el) {
+ConvPlan make_plan(int Cin, int Cout, int KH, int KW, int pad, int dil, int el, int bn) {
     ConvPlan p;
     p.el = el;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad_h = pad; p.pad_w = pad; p.dil = dil;
     p.Cin_pad = cdiv(Cin, 32) * 32;
-    p.BN = conv_plan_bn(Cout);
+    p.BN = bn > 0 ? bn : conv_plan_bn(Cout);
     p.Cout_pad = cdiv(Cout, p.BN) * p.BN;
     return p;
 }
@@ -94,14 +94,14 @@ static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, Conv
 }
 
 static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std::string& conv, const std::string& bn, int Cin, int Cout,
-                       int K, int pad, int dil, int el, bool split = false) {
+                       int K, int pad, int dil, int el, bool split = false, int tile_bn = 0) {
     std::vector<float> w, b;
     fold_conv(tm, conv, bn, Cout, Cin, K * K, w, b);
     if (split) {
         upload_split_plan(c, p, Cin, Cout, K, K, pad, w, b);
         return;
     }
-    p = make_plan(Cin, Cout, K, K, pad, dil, el);
+    p = make_plan(Cin, Cout, K, K, pad, dil, el, tile_bn);
     upload_plan(c, p, w, b);
 }
 
@@ -198,8 +198,11 @@ void load_craft(bbocr_ctx* c, const TensorMap& tm) {
     load_layer(c, tm, c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1, det_el(c));
     load_layer(c, tm, c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1, det_el(c));
     load_layer(c, tm, c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6, det_el(c));
-    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1, det_el(c));
-    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1, det_el(c));
+    // the long-K 1x1 GEMMs run 256-cout tiles (8 waves): their 128-cout tiles moved 24 KB of LDS-DMA per 2.1 MFLOP k-step and sat at the
+    // DMA fill rate (~8 TB/s, 0.71 PFLOP/s); 32 KB per 4.2 MFLOP now
+    static const int bn1x1 = diag_knob("BBOCR_BN256_1X1", 1) ? 256 : 0;
+    load_layer(c, tm, c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1, det_el(c), false, bn1x1);
+    load_layer(c, tm, c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1, det_el(c), false, bn1x1);
     load_layer(c, tm, c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1, det_el(c));
     load_split_1x1(c, tm, c->up2y, c->up2s, "upconv2.conv.0", "upconv2.conv.1", 256, 512, 256);
     load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1, det_el(c));
@@ -272,7 +275,7 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
             c->whh_scale[l] = pack_lstm_whh_split(hf, hb, pk.data());
             c->whh[l] = upload(c, pk);
         } else {
-            c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1, rec_el(c));
+            c->xproj[l] = make_plan(256, 2048, 1, 1, 0, 1, rec_el(c), diag_knob("BBOCR_BN256_XPROJ", 1) ? 256 : 0);
             upload_plan(c, c->xproj[l], w, b);
             std::vector<uint16_t> pk(lstm_whh_packed_elems());
             pack_lstm_whh8(hf, hb, pk.data(), rec_el(c));
@@ -283,7 +286,7 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
         if (rec_split(c)) {
             upload_split_plan(c, c->lin[l], 512, 256, 1, 1, 0, lw, lb, 1.f);     // reads lstm_exact_kernel's pair: lo = fp16(h - hi), unscaled
         } else {
-            c->lin[l] = make_plan(512, 256, 1, 1, 0, 1, rec_el(c));
+            c->lin[l] = make_plan(512, 256, 1, 1, 0, 1, rec_el(c), diag_knob("BBOCR_BN256_LIN", 1) ? 256 : 0);
             upload_plan(c, c->lin[l], lw, lb);
         }
     }
