@@ -29,6 +29,17 @@
 #define CONV_DBG(a, bit) false
 #endif
 
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4: lane l's 16 bytes land at lds + 16 l), issued as inline assembly.  The builtin
+// (__builtin_amdgcn_global_load_lds) is modelled by hipcc's waitcnt pass as a FLAT access that touches LDS: while one is outstanding -- in
+// these kernels always, their vmcnt waits are counted, never 0 -- every LDS dependency is waited for with a full `s_waitcnt lgkmcnt(0)`,
+// so ds_reads issued ahead of their use could never stay in flight across an MFMA group.  Behind the asm the compiler tracks only the
+// ds_reads (counted lgkmcnt); ordering against the DMA'd bytes is what the kernels' explicit `s_waitcnt vmcnt(N)` + s_barrier do anyway.
+// `lds` must be wave-uniform.  M0 is written here and by nothing else in these kernels.
+__device__ __forceinline__ void lds_dma16(const void* gptr, const void* lds) {
+    const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(la) : "memory");
+}
+
 // ---- shared epilogue: bias (+ReLU) (+fused max-pool).  Lane (pixel pl, group g) holds, per 16-pixel fragment, 16 outputs
 // acc[j][r]; the cout permutation of pack_conv_weights maps them to cout = tile + wn*64 + (j>>1)*32 + g*8 + (j&1)*4 + r:
 // TWO runs of 8 contiguous couts, 32 apart, so that one store instruction writes, for every pixel, 64 contiguous bytes
@@ -316,6 +327,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
     else pooled(std::integral_constant<int, 4>{});
 }
 
+// Epilogue of the fused conv1_1 + conv1_2 launch (16 x 16 tiles, 64 couts, bias + ReLU + MaxPool2d(2,2), only the pooled tensor is kept):
+// the max over the 2x2 window is taken FIRST, on the raw accumulators -- x -> max(fma(x, sc, b), floor) is monotone for sc > 0, so the
+// result is bit-identical to pooling the finished values (conv_epilogue) -- then ONE bias / ReLU / pack per pooled value instead of
+// four, and each lane of a pixel pair finishes only the run it stores (even lane run 0, odd lane run 1: whole 128-byte lines).  The kernel
+// carries none of the shared epilogue's variants: it was vector-issue bound with ~300 of its 1,170 VALU instructions per wave in here.
+template <int EL, int MF>
+__device__ __forceinline__ void conv_epilogue_pool2x2_lean(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int oy0, int ox0, int wm, int lane) {
+    static_assert(MF % 2 == 0, "fragment f and f + 1 are the two rows of a pooling window");
+    const int g = lane >> 4, pl = lane & 15, odd = pl & 1;
+    const int cout0 = g * 8;
+    const float sc = a.acc_scale;
+    const float floor_v = (a.relu_out || a.pool_relu) ? 0.f : -__builtin_inff();
+    float bsel[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + odd * 32 + q * 4);
+        bsel[q * 4 + 0] = b4[0]; bsel[q * 4 + 1] = b4[1]; bsel[q * 4 + 2] = b4[2]; bsel[q * 4 + 3] = b4[3];
+    }
+    const int POH = a.OH >> 1, POW = a.OW >> 1;
+    const int px = (ox0 + pl) >> 1;
+#pragma unroll
+    for (int f = 0; f < MF; f += 2) {
+        const int py = (oy0 + wm * MF + f) >> 1;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int i1 = 8 + i;
+            float q0 = fmaxf(acc[f][i >> 2][i & 3], acc[f + 1][i >> 2][i & 3]);
+            float q1 = fmaxf(acc[f][i1 >> 2][i1 & 3], acc[f + 1][i1 >> 2][i1 & 3]);
+            q0 = fmaxf(q0, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q0), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true)));
+            q1 = fmaxf(q1, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q1), 0xB1, 0xF, 0xF, true)));
+            o[i] = fmaxf(fmaf(odd ? q1 : q0, sc, bsel[i]), floor_v);
+        }
+        const u32x4 pk = {El<EL>::pack2(o[0], o[1]), El<EL>::pack2(o[2], o[3]), El<EL>::pack2(o[4], o[5]), El<EL>::pack2(o[6], o[7])};
+        uint16_t* op = (uint16_t*)a.pool_out + ((size_t)(n * POH + py) * POW + px) * a.pool_cs + cout0 + odd * 32;
+        if (py < POH && px < POW) *(u32x4*)op = pk;
+    }
+}
+
 // Generic register-staged variant (any kernel size / dilation / pooling): 256-thread workgroups built for TWO co-resident
 // workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
 template <int EL, int WM, int WN, int MF, int PITER>
@@ -540,7 +590,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int wm = wave / WN, wn = wave % WN;
     const int sub = a.sub;
     const int nk = a.nchunks * 9;
-    const int fpr = a.TW >> 4;
+    // the fused conv1_2 kernel always runs 16 x 16 tiles (18-pixel patch rows): compile-time, so that every fragment read of the k-loop is
+    // one base register + an immediate offset
+    const int fpr = FUSE1 ? 1 : a.TW >> 4;
+    const int PW = FUSE1 ? 18 : a.PW;
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // dilation d (a.sub) with padding d == d*d independent plain 3x3 convs on the phase sub-lattices: image index n' enumerates
@@ -607,22 +660,18 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         const int cb = (s0 ? c : c - a.C0) + wave * 8;
         const uint16_t* gp = sp >= 0 ? src + (size_t)sp * cs + cb : (const uint16_t*)a.zero;
         if ((pb + 1) * 64 <= NPS || pb * 64 + lane < NPS)     // (still one vmcnt event per wave: every wave has lanes below NPS)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(pbuf + par * patch_bytes + (wave * NP + pb * 64) * 16),
-                                             16, 0, 0);
+            lds_dma16(gp, pbuf + par * patch_bytes + (wave * NP + pb * 64) * 16);
     };
     auto issue_w = [&](const unsigned char* slice, int slot) {
 #pragma unroll
-        for (int p0 = 0; p0 < WPIECES; p0 += NT)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slice + (size_t)(p0 + tid) * 16),
-                                             (__attribute__((address_space(3))) void*)(wbuf + slot * WBUF + (p0 + wave * 64) * 16), 16, 0, 0);
+        for (int p0 = 0; p0 < WPIECES; p0 += NT) lds_dma16(slice + (size_t)(p0 + tid) * 16, wbuf + slot * WBUF + (p0 + wave * 64) * 16);
     };
     int frag_off[MF];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
         const int F = wm * MF + f;
         const int fr = F / fpr, fc = F - fr * fpr;
-        frag_off[f] = (fr * a.PW + fc * 16) * 16;
+        frag_off[f] = (fr * PW + fc * 16) * 16;
     }
     const int lane_patch_off = ((lane >> 4) * NP + (lane & 15)) * 16;
     const int lane_w_off = wn * 4 * 1024 + lane * 16;
@@ -693,14 +742,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
             for (int j = 0; j < 4; ++j) w1[ks1][j] = *(const typename El<EL>::v8*)(a.c11_w + ((size_t)(ks1 * 4 + j) * 64 + lane) * 8);
         const int g = lane >> 4, pl = lane & 15;
-        float b1[16];
+        f32x4 b1[4];                                    // conv1_1's bias in accumulator layout: the first MFMA of a fragment takes it as C
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int q4 = 0; q4 < 2; ++q4) {
-                const f32x4 bv = *(const f32x4*)(a.c11_b + h * 32 + g * 8 + q4 * 4);
-                b1[h * 8 + q4 * 4 + 0] = bv[0]; b1[h * 8 + q4 * 4 + 1] = bv[1]; b1[h * 8 + q4 * 4 + 2] = bv[2]; b1[h * 8 + q4 * 4 + 3] = bv[3];
-            }
+            for (int q4 = 0; q4 < 2; ++q4) b1[h * 2 + q4] = *(const f32x4*)(a.c11_b + h * 32 + g * 8 + q4 * 4);
         __builtin_amdgcn_sched_barrier(0);              // loads above, their consumers below
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -744,21 +790,18 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             }
             f32x4 d[3][4];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
             for (int ks1 = 0; ks1 < 2; ++ks1)
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[q][j] = El<EL>::mfma(w1[ks1][j], bfr[q][ks1], d[q][j]);
+                    for (int j = 0; j < 4; ++j) d[q][j] = El<EL>::mfma(w1[ks1][j], bfr[q][ks1], ks1 ? d[q][j] : b1[j]);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int fi = wave + (b3 * 3 + q) * NW;
                 const int pp = pps[q];
                 const int iy = cur.oy0 - 1 + pys[q], ix = cur.ox0 - 1 + pxs[q];
                 const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;     // else: conv1_2's own zero padding
+                const float cap = inside ? __builtin_inff() : 0.f;                  // ReLU and the padding mask as one v_med3: med3(x, 0, cap)
                 if (fi < 21 && pp < 324) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -766,8 +809,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int k = h * 8 + i * 2;
-                            const float x0 = fmaxf(d[q][k >> 2][k & 3] + b1[k], 0.f), x1 = fmaxf(d[q][(k + 1) >> 2][(k + 1) & 3] + b1[k + 1], 0.f);
-                            o[i] = inside ? El<EL>::pack2(x0, x1) : 0u;
+                            const float x0 = __builtin_amdgcn_fmed3f(d[q][k >> 2][k & 3], 0.f, cap), x1 = __builtin_amdgcn_fmed3f(d[q][(k + 1) >> 2][(k + 1) & 3], 0.f, cap);
+                            o[i] = El<EL>::pack2(x0, x1);
                         }
                         *(u32x4*)(pbuf + h * patch_bytes + (g * NP + pp) * 16) = o;
                     }
@@ -786,9 +829,30 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // One k-step.  MORE: a chunk follows (its patch is prefetched, weight slices keep streaming).
+    // Fragment schedule (pinned with sched_barrier: left to itself hipcc keeps two B fragments live and puts a full `s_waitcnt lgkmcnt(0)`
+    // LDS round trip in front of every group of 8 MFMAs -- four exposed round trips per k-step, ~500 of its ~1,250 cycles):
+    //   [A(t) x NF][DMA issue] | MFMA group 0 | read B 4,5 | group 1 | read B 6,7 | group 2 | read B'0,1 | group 3 | read B'2,3 | barrier
+    // group g = fragments 2g, 2g+1 x all couts; B' = the NEXT tap's first four fragments: the patch of a chunk is stable across its nine
+    // taps, so they are read ahead of the barrier (only the weight slice needs it).  Every read has a group (8 MFMAs, 128 cycles) to land.
+    // Tap 0 of a chunk reads its first four fragments itself (new patch buffer, ReLU pass).
+    static_assert(MF % 2 == 0 && MF >= 4, "B fragments are scheduled in pairs, four ahead");
+    typename El<EL>::v8 pre[4];
     auto step = [&](auto tap_c, auto more_c, int c) {
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool MORE = decltype(more_c)::value;
+        constexpr int ky = tap / 3, kx = tap % 3;
+        const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
+        const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * PW + kx) * 16;
+        typename El<EL>::v8 af[NF], bq[MF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
+        if constexpr (tap == 0) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bq[f] = pre[f];
+        }
         if constexpr (Sched::wcnt(MORE, tap) > 0) {
             int slot = wslot + RING - 1;
             if (slot >= RING) slot -= RING;
@@ -801,19 +865,26 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             issue_p(spix[p0], nc, par ^ 1, std::integral_constant<int, p0>{});
             if constexpr (Sched::pcnt(tap) > 1) issue_p(spix[p0 + 1], nc, par ^ 1, std::integral_constant<int, p0 + 1>{});
         }
-        constexpr int ky = tap / 3, kx = tap % 3;
-        const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
-        const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * a.PW + kx) * 16;
-        typename El<EL>::v8 af[NF], bq[MF];
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int kyn = (tap + 1) / 3, kxn = (tap + 1) % 3;
+        const unsigned char* pbn = pbuf + par * patch_bytes + lane_patch_off + (kyn * PW + kxn) * 16;
 #pragma unroll
-        for (int j = 0; j < NF; ++j) af[j] = *(const typename El<EL>::v8*)(wb + j * 1024);
+        for (int g = 0; g < MF / 2; ++g) {
 #pragma unroll
-        for (int f = 0; f < MF; ++f) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
+            for (int f = 2 * g; f < 2 * g + 2; ++f)
 #pragma unroll
-        for (int f = 0; f < MF; ++f)
+                for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
+            for (int f = 2 * g + 4; f < 2 * g + 6; ++f) {
+                if (f < MF) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
+                else if constexpr (tap < 8) pre[f - MF] = *(const typename El<EL>::v8*)(pbn + frag_off[f - MF]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (no lgkmcnt here: this step's weight fragments were consumed by its MFMAs, the reads still in flight are the next tap's B
+        // fragments from the patch buffer nobody writes during this chunk)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Sched::younger(MORE, tap)) : "memory");
         wslot = wslot + 1 == RING ? 0 : wslot + 1;
     };
     // ReLU-on-load (the input is a BatchNorm-terminated VGG slice, conv3_3 / conv4_3): applied ONCE per chunk, in place in the LDS patch,
@@ -845,7 +916,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         return;
     }
 #endif
-    conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+    if constexpr (FUSE1) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, lane);       // (launch_dma checks its preconditions)
+    else conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
 #ifdef BBOCR_DIAG
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
 #endif
@@ -1445,7 +1517,10 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
         // trimmed to its 18 x 18 = 324 pixels and a 3-deep weight ring are 53,760 B of LDS (3 x 53,760 <= 160 KB)
         static const bool three = (diag_knob("BBOCR_CONV_3WG", 1) != 0);
         if (a.c11_w) {   // conv1_2 with the conv1_1 producer fused in
-            if (!(npb == 6 && a.PH * a.PW == 324 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
+            if (!(npb == 6 && a.PH == 18 && a.PW == 18 && a.TH == 16 && a.TW == 16 && a.nchunks == 2 && a.sub == 1)) return hipErrorInvalidValue;
+            // the kernel's only epilogue: 64 stored couts, MaxPool2d(2,2) fused, nothing but the pooled 16-bit tensor kept
+            if (!(a.pool_mode == 1 && !a.store_full && !a.split_off && !a.out_f32 && !a.tail && a.cout_store == 64 && a.ntiles_n == 1 && a.acc_scale > 0.f))
+                return hipErrorInvalidValue;
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, true>(a, grid, s);
         }
         if (three && npb == 6 && a.PH * a.PW == 324) {
