@@ -974,6 +974,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) 
             for (int c = 0; c < NCH; ++c) {
                 const uint16_t* gp = ok ? a.in0 + sp + c * 32 : (const uint16_t*)a.zero;
                 if ((pb + 1) * 64 <= NP || pix < NP)
+                    // (the builtin, not lds_dma16: with counted lgkmcnt waits hipcc's schedule of this unrolled tile body measured 10 % slower)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                      (__attribute__((address_space(3))) void*)(pbuf + (buf * NCH + c) * PCH + (wave * NP + pb * 64) * 16), 16, 0, 0);
             }
@@ -1102,8 +1103,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k2 = 0; k2 < NK / 2; ++k2) {
             const int ks = k2 * 2 + (wave >> 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16),
-                                             (__attribute__((address_space(3))) void*)(wres + ks * WSL + (wave & 1) * 1024), 16, 0, 0);
+            lds_dma16(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16, wres + ks * WSL + (wave & 1) * 1024);
         }
     }
     // 1x1 weights: packed slice c (32 input channels) x fragment j (16 couts in the epilogue's run order) -> registers for the whole launch
@@ -1318,9 +1318,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) conv1x1_
     auto issue = [&](int ks, int slot) {
         unsigned char* sb = smem + slot * SLOT;
 #pragma unroll
-        for (int p0 = 0; p0 < WPIECES; p0 += NT)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16),
-                                             (__attribute__((address_space(3))) void*)(sb + (p0 + wave * 64) * 16), 16, 0, 0);
+        for (int p0 = 0; p0 < WPIECES; p0 += NT) lds_dma16(wsrc + (size_t)ks * WBUF + (size_t)(p0 + tid) * 16, sb + (p0 + wave * 64) * 16);
         const int c = ks * 32;
         const bool s0 = c < a.C0;
         const uint16_t* src = s0 ? a.in0 : a.in1;
@@ -1329,8 +1327,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) conv1x1_
 #pragma unroll
         for (int i = 0; i < PBW; ++i) {
             const uint16_t* g = pix[i] >= 0 ? src + (size_t)pix[i] * cs + cb : (const uint16_t*)a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(sb + WBUF + (kg * NPX + (pb0 + i) * 64) * 16), 16, 0, 0);
+            lds_dma16(g, sb + WBUF + (kg * NPX + (pb0 + i) * 64) * 16);
         }
     };
     const int lane_p_off = WBUF + ((lane >> 4) * NPX + (lane & 15)) * 16 + wm * MF * 256;
@@ -1353,6 +1350,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) conv1x1_
             issue(ks + RING - 1, sl);
         }
         const unsigned char* sb = smem + slot * SLOT;
+        // (the pair-wise read-ahead schedule of conv3x3_dma_kernel measured SLOWER here -- fc7 393 -> 446 us: every k-step brings new A and
+        // new B fragments, nothing can be read across the barrier, and the reads it spreads out delay the next DMA issue)
         typename El<EL>::v8 af[4], bq[MF];
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[j] = *(const typename El<EL>::v8*)(sb + lane_w_off + j * 1024);
