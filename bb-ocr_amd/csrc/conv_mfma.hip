@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 // issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
 // FUSE1 (CRAFT conv1_2 only: Cin = 64, 16x16 tiles, BN = 64): the 64-channel input patch is not read from memory but PRODUCED
 // in the prologue from the uint8 RGB page -- normalizeMeanVariance + conv1_1 (3x3, 3->64) + BN + ReLU, one 27-deep (padded
-// to 64) MFMA product per 16 patch pixels -- and written straight into the two LDS patch buffers (both 32-channel chunks are
+// to 32: a single k-step) MFMA product per 16 patch pixels -- and written straight into the two LDS patch buffers (both 32-channel chunks are
 // resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
 // NF (cout fragments a wave multiplies, 4 or 2): layers with <= 32 real couts in a 64-cout tile (up4b, conv_cls.0/.2/.4) skip the two
 // fragments that are pure padding (couts 32..63 of the tile, see the cout mapping of the epilogue) -- half the MFMAs, same results.
@@ -734,13 +734,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
             cr[it] = q[0]; cg[it] = q[1]; cb[it] = q[2];
             if (!on_page) { cr[it] = 0u; cg[it] = 0u; cb[it] = 0u; }
         }
-        // conv1_1 weights as MFMA A fragments: K = tap*4 + channel padded to 64 (two k-steps), couts in the run order of the
+        // conv1_1 weights as MFMA A fragments: one 32-deep k-step (layout: pack_conv1_1_weights_fused), couts in the run order of the
         // epilogue mapping, so that a lane's 16 outputs are exactly one 16-byte slot of each 32-channel chunk of the patch image
-        typename El<EL>::v8 w1[2][4];
+        typename El<EL>::v8 w1[4];
 #pragma unroll
-        for (int ks1 = 0; ks1 < 2; ++ks1)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w1[ks1][j] = *(const typename El<EL>::v8*)(a.c11_w + ((size_t)(ks1 * 4 + j) * 64 + lane) * 8);
+        for (int j = 0; j < 4; ++j) w1[j] = *(const typename El<EL>::v8*)(a.c11_w + ((size_t)j * 64 + lane) * 8);
         const int g = lane >> 4, pl = lane & 15;
         f32x4 b1[4];                                    // conv1_1's bias in accumulator layout: the first MFMA of a fragment takes it as C
 #pragma unroll
@@ -761,9 +759,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         }
         __syncthreads();
         // (2) 21 fragments of 16 patch pixels (18 x 18 = 324 = 20*16 + 4), dealt round-robin to the four waves.  A fragment is a
-        //     latency chain (LDS reads -> 8 MFMAs -> bias / ReLU / pack -> LDS write, ~1,300 cycles on its own -- the tile timeline
+        //     latency chain (LDS reads -> 4 MFMAs -> ReLU / pack -> LDS write, ~1,300 cycles on its own -- the tile timeline
         //     showed 7.8 k cycles for the 5-6 fragments of a wave); the fragments of a wave are independent, so they run as TWO
-        //     interleaved batches of three: all B operands of a batch are read first, then its 24 MFMAs, then the three epilogues.
+        //     interleaved batches of three: all B operands of a batch are read first, then its 12 MFMAs, then the three epilogues.
         auto frag_geo = [&](int fi, int& pp, int& py, int& px) {
             pp = fi * 16 + pl;
             py = pp / 18;
@@ -771,30 +769,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         };
 #pragma unroll
         for (int b3 = 0; b3 < 2; ++b3) {
-            typename El<EL>::v8 bfr[3][2];
+            typename El<EL>::v8 bfr[3];
             int pps[3], pys[3], pxs[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int fi = wave + (b3 * 3 + q) * NW;         // fi >= 21: nothing is stored, the operands only need valid addresses
                 frag_geo(fi < 21 ? fi : 20, pps[q], pys[q], pxs[q]);
                 const int pc = pps[q] < 324 ? pys[q] * 20 + pxs[q] : 0;
-#pragma unroll
-                for (int ks1 = 0; ks1 < 2; ++ks1) {
-                    int t0 = ks1 * 8 + 2 * g, t1 = t0 + 1;
-                    t0 = t0 > 8 ? 8 : t0;                        // taps >= 9 meet zero weights; any valid address will do
-                    t1 = t1 > 8 ? 8 : t1;
-                    const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
-                    const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
-                    bfr[q][ks1] = __builtin_bit_cast(typename El<EL>::v8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
-                }
+                // K = 32 in one k-step: taps 2g, 2g+1 as [r g b X | r g b Y], the ninth tap's r / g / b in the pad slots X(g=0) / Y(g=0) / X(g=1)
+                // (pack_conv1_1_weights_fused); a stored pixel is {r | g << 16, b | 0 << 16}
+                const int t0 = 2 * g, t1 = t0 + 1;
+                const u32x2 a0 = rgbp[pc + (t0 / 3) * 20 + (t0 % 3)];
+                const u32x2 a1 = rgbp[pc + (t1 / 3) * 20 + (t1 % 3)];
+                const u32x2 t8 = rgbp[pc + 2 * 20 + 2];
+                const unsigned int x = g == 0 ? (t8[0] << 16) : (g == 1 ? (t8[1] << 16) : 0u);
+                const unsigned int y = g == 0 ? (t8[0] & 0xffff0000u) : 0u;
+                bfr[q] = __builtin_bit_cast(typename El<EL>::v8, (u32x4){a0[0], a0[1] | x, a1[0], a1[1] | y});
             }
             f32x4 d[3][4];
 #pragma unroll
-            for (int ks1 = 0; ks1 < 2; ++ks1)
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) d[q][j] = El<EL>::mfma(w1[ks1][j], bfr[q][ks1], ks1 ? d[q][j] : b1[j]);
+                for (int j = 0; j < 4; ++j) d[q][j] = El<EL>::mfma(w1[j], bfr[q], b1[j]);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int fi = wave + (b3 * 3 + q) * NW;

@@ -10,20 +10,24 @@
 // padded 36 -> 64 (two MFMA k-steps); fragment nf, row -> cout (nf>>1)*32 + (row>>2)*8 + (nf&1)*4 + (row&3), the run order of the
 // conv epilogue.  el: element type of the packed fragments (0 bf16, 1 fp16).
 void pack_conv1_1_weights_fused(const float* w, uint16_t* out, int el) {
+    // ONE 32-deep k-step for the 27 (tap, channel) products: lane group g carries taps 2g and 2g+1 as [r g b X | r g b Y] -- the patch
+    // pixels are stored as four 16-bit values r g b 0 -- and the ninth tap rides in the pad slots: X(g=0) = tap 8 r, Y(g=0) = tap 8 g,
+    // X(g=1) = tap 8 b (conv3x3_dma_kernel<FUSE1> builds the matching B fragment)
     size_t o = 0;
-    for (int s = 0; s < 2; ++s)
-        for (int nf = 0; nf < 4; ++nf)
-            for (int l = 0; l < 64; ++l) {
-                const int row = l & 15;
-                const int cout = (nf >> 1) * 32 + (row >> 2) * 8 + (nf & 1) * 4 + (row & 3);
-                for (int j = 0; j < 8; ++j) {
-                    const int k = s * 32 + 8 * (l >> 4) + j;
-                    const int tap = k >> 2, ch = k & 3;
-                    float v = 0.f;
-                    if (tap < 9 && ch < 3) v = w[((size_t)cout * 3 + ch) * 9 + tap];
-                    out[o++] = f32_to_el_host(el, v);
+    for (int nf = 0; nf < 4; ++nf)
+        for (int l = 0; l < 64; ++l) {
+            const int row = l & 15, g = l >> 4;
+            const int cout = (nf >> 1) * 32 + (row >> 2) * 8 + (nf & 1) * 4 + (row & 3);
+            for (int j = 0; j < 8; ++j) {
+                int tap = 2 * g + (j >> 2), ch = j & 3;
+                if (ch == 3) {
+                    tap = 8;
+                    ch = (g == 0) ? (j == 3 ? 0 : 1) : ((g == 1 && j == 3) ? 2 : -1);
                 }
+                const float v = ch >= 0 ? w[((size_t)cout * 3 + ch) * 9 + tap] : 0.f;
+                out[o++] = f32_to_el_host(el, v);
             }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ max-pool

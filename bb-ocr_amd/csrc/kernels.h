@@ -74,7 +74,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zer
 hipError_t launch_up4_fused(const ConvPlan& p1, const ConvPlan& p3, ConvArgs a, hipStream_t s);
 
 // ------------------------------------------------------------------ detector front/back (craft_misc.hip)
-void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[2][4][64][8]*/, int el);   // K = tap*4 + channel, couts in the conv epilogue's run order
+void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[4][64][8]*/, int el);   // one k-step: taps 2g, 2g+1 per lane group, tap 8 in the pad slots; couts in the conv epilogue's run order
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);

@@ -181,7 +181,7 @@ void load_craft(bbocr_ctx* c, const TensorMap& tm) {
     {
         std::vector<float> w, b;
         fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);
-        std::vector<uint16_t> pk(2 * 4 * 64 * 8);
+        std::vector<uint16_t> pk(4 * 64 * 8);
         pack_conv1_1_weights_fused(w.data(), pk.data(), det_el(c));
         c->c11_wf = upload(c, pk);
         c->c11_b = upload(c, b);
