@@ -366,6 +366,77 @@ __device__ __forceinline__ void conv_epilogue_pool2x2_lean(const ConvArgs& a, f3
     }
 }
 
+// Epilogue with a 1x1 conv 64 -> 64 behind the layer (a.post_w; 64-cout tiles whose wave holds all 64 channels of its pixels): the cout
+// permutation makes a lane's finished values v[0..7] / v[8..15] exactly the B fragment (k = 8g + i) of channels 0-31 / 32-63 for the
+// next MFMA, so z = W u costs two k-steps x four cout fragments per 16 pixels and u itself is never stored.  Same arithmetic as the
+// separate 1x1 launch (u rounded to the element type, chunk 0 then chunk 1 accumulated in fp32): bit-identical z.
+template <int EL, int MF>
+__device__ __forceinline__ void conv_epilogue_post1x1(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int oy0, int ox0, int wm, int fpr, int lane) {
+    const int g = lane >> 4, pl = lane & 15;
+    const int cout0 = g * 8;
+    const float sc = a.acc_scale;
+    const float floor_v = a.relu_out ? 0.f : -__builtin_inff();
+    float bs[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + h * 32 + q * 4);
+            bs[h * 8 + q * 4 + 0] = b4[0]; bs[h * 8 + q * 4 + 1] = b4[1]; bs[h * 8 + q * 4 + 2] = b4[2]; bs[h * 8 + q * 4 + 3] = b4[3];
+        }
+    typename El<EL>::v8 wf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[ks][j] = *(const typename El<EL>::v8*)(a.post_w + ((size_t)(ks * 4 + j) * 64 + lane) * 8);
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int F = wm * MF + f;
+        const int fr = F / fpr, fc = F - fr * fpr;
+        const int oy = oy0 + fr, xb = ox0 + fc * 16;
+        u32x4 bk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = h * 8 + i * 2;
+                const float x0 = fmaxf(fmaf(acc[f][k >> 2][k & 3], sc, bs[k]), floor_v), x1 = fmaxf(fmaf(acc[f][(k + 1) >> 2][(k + 1) & 3], sc, bs[k + 1]), floor_v);
+                bk[h][i] = El<EL>::pack2(x0, x1);
+            }
+        f32x4 y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = El<EL>::mfma(wf[0][j], __builtin_bit_cast(typename El<EL>::v8, bk[0]), (f32x4){0.f, 0.f, 0.f, 0.f});
+            y[j] = El<EL>::mfma(wf[1][j], __builtin_bit_cast(typename El<EL>::v8, bk[1]), y[j]);
+        }
+        // whole-line stores as in conv_epilogue (fullw): run 0 / run 1 of a pixel regrouped across lanes pl <-> pl ^ 8
+        const u32x4 lo = {El<EL>::pack2(y[0][0], y[0][1]), El<EL>::pack2(y[0][2], y[0][3]), El<EL>::pack2(y[1][0], y[1][1]), El<EL>::pack2(y[1][2], y[1][3])};
+        const u32x4 hi = {El<EL>::pack2(y[2][0], y[2][1]), El<EL>::pack2(y[2][2], y[2][3]), El<EL>::pack2(y[3][0], y[3][1]), El<EL>::pack2(y[3][2], y[3][3])};
+        u32x4 dA, dB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dA[i] = (unsigned)__builtin_amdgcn_update_dpp((int)lo[i], (int)hi[i], 0x118 /*row_shr:8*/, 0xF, 0xC, false);
+            dB[i] = (unsigned)__builtin_amdgcn_update_dpp((int)hi[i], (int)lo[i], 0x108 /*row_shl:8*/, 0xF, 0x3, false);
+        }
+        const int co = cout0 + (pl >> 3) * 32;
+        const int xA = xb + (pl & 7), xB = xb + 8 + (pl & 7);
+        uint16_t* op = (uint16_t*)a.out + (size_t)(n * a.OH + oy) * a.OW * a.out_cs + co;
+        if (oy < a.OH && xA < a.OW) *(u32x4*)(op + (size_t)xA * a.out_cs) = dA;
+        if (oy < a.OH && xB < a.OW) *(u32x4*)(op + (size_t)xB * a.out_cs) = dB;
+    }
+}
+
+void pack_post1x1_weights(const float* w, uint16_t* out, int el) {
+    size_t o = 0;
+    for (int ks = 0; ks < 2; ++ks)
+        for (int nf = 0; nf < 4; ++nf)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 15;
+                const int cout = (nf >> 1) * 32 + (row >> 2) * 8 + (nf & 1) * 4 + (row & 3);       // the epilogue's run order (pack_conv_weights)
+                for (int j = 0; j < 8; ++j) out[o++] = f32_to_el_host(el, w[(size_t)cout * 64 + ks * 32 + 8 * (l >> 4) + j]);
+            }
+}
+
 // Generic register-staged variant (any kernel size / dilation / pooling): 256-thread workgroups built for TWO co-resident
 // workgroups per CU (launch bound 2 waves/SIMD = 256 VGPRs) whose LDS-read and MFMA phases overlap each other.
 template <int EL, int WM, int WN, int MF, int PITER>
@@ -568,7 +639,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 // resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
 // NF (cout fragments a wave multiplies, 4 or 2): layers with <= 32 real couts in a 64-cout tile (up4b, conv_cls.0/.2/.4) skip the two
 // fragments that are pure padding (couts 32..63 of the tile, see the cout mapping of the epilogue) -- half the MFMAs, same results.
-template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
@@ -913,6 +984,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     }
 #endif
     if constexpr (FUSE1) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, lane);       // (launch_dma checks its preconditions)
+    else if constexpr (EPI == 1) conv_epilogue_post1x1<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, fpr, lane);                  // (launch_dma checks its preconditions)
     else conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
 #ifdef BBOCR_DIAG
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
@@ -1463,9 +1535,9 @@ static const char* conv_stamps_dir() {
 #endif
 }
 
-template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<EL, WM, WN, MF, NPB, RING, NPS, FUSE1, NF>;
+    auto k = conv3x3_dma_kernel<EL, WM, WN, MF, NPB, RING, NPS, FUSE1, NF, EPI>;
     const size_t smem_max = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     // a single 32-channel chunk (conv_cls: Cin = 32) never touches the second patch buffer: without it a workgroup needs 33 KB and
     // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
@@ -1518,6 +1590,12 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
                 return hipErrorInvalidValue;
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, true>(a, grid, s);
         }
+        if (a.post_w) {   // 1x1 64 -> 64 behind the layer: 16 x 16 tiles of a plain 64-cout layer only, anything else is declined
+            if (!(WN == 1 && three && npb == 6 && a.PH == 18 && a.PW == 18 && a.cout_store == 64 && a.ntiles_n == 1 && a.sub == 1 && !a.pool_mode &&
+                  !a.split_off && !a.out_f32 && !a.tail && !a.addup))
+                return hipErrorNotSupported;
+            if constexpr (WN == 1) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 4, 1>(a, grid, s);
+        }
         if (three && npb == 6 && a.PH * a.PW == 324) {
             static const bool half = (diag_knob("BBOCR_CONV_NF2", 1) != 0);   // A/B knob
             static const bool resw = (diag_knob("BBOCR_CONV_RESW", 1) != 0);    // A/B knob
@@ -1526,8 +1604,10 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
             if (half && a.cout_store <= 32) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324>(a, grid, s);
         }
+        if (a.post_w) return hipErrorNotSupported;
         if (npb == 6) return launch_dma_one<EL, WM, WN, MF, 6, 3>(a, grid, s);      // measured faster than the 4-deep ring at this tile
     }
+    if (a.post_w) return hipErrorNotSupported;
     if (npb == 6) return r4 ? launch_dma_one<EL, WM, WN, MF, 6, 4>(a, grid, s) : launch_dma_one<EL, WM, WN, MF, 6, 3>(a, grid, s);
     if (npb == 7) return launch_dma_one<EL, WM, WN, MF, 7, 3>(a, grid, s);
     return hipErrorInvalidValue;
@@ -1549,6 +1629,9 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     if (a.OH <= 0 || a.OW <= 0) return hipErrorInvalidValue;
     a.ntaps = p.KH * p.KW;
     a.sub = 1;
+    // a 1x1 behind the layer (a.post_w) exists for plain 3x3 layers with one 64-cout tile on the LDS-DMA kernel; the caller falls back to two launches
+    if (a.post_w && !(conv_dma() && a.zero && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && BN == 64 && p.Cout_pad == 64))
+        return hipErrorNotSupported;
     if (conv_dma() && a.zero && !a.pool_mode && p.KH == 3 && p.KW == 3 && p.dil > 1 && p.pad_h == p.dil && p.pad_w == p.dil) {
         const int d = p.dil, LH = cdiv(a.OH, d), LW = cdiv(a.OW, d);   // phase sub-lattice size
         long long best = -1;
@@ -1629,6 +1712,7 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
             return BN == 128 ? launch_dma<EL, 2, 2, 8>(a, npb, grid, s) : launch_dma<EL, 4, 1, 4>(a, npb, grid, s);
         }
     }
+    if (a.post_w) return hipErrorNotSupported;
     const int piter = cdiv(a.NP / 16, NWV);
     if (BN == 128) return piter <= 4 ? launch_cfg<EL, 2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 2, 2, 8, 8>(a, grid, s) : launch_cfg<EL, 2, 2, 8, 16>(a, grid, s));
     if (BN == 64) return piter <= 4 ? launch_cfg<EL, 4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 4, 1, 4, 8>(a, grid, s) : launch_cfg<EL, 4, 1, 4, 16>(a, grid, s));

@@ -144,6 +144,7 @@ struct bbocr_ctx {
     ConvPlan up2y, up2s, up3y, up3s, up4y, up4s;
     float* cls_tail = nullptr;   // b1[16] w2[32] b2[2]
     uint16_t* cls_tail_frag = nullptr;   // conv_cls.6 weight as an MFMA A fragment
+    uint16_t* up4y_post = nullptr;       // upconv4's 1x1, y half (64 -> 64), as the A fragments of the 1x1 applied in upconv3.3x3's epilogue
     // ---- recogniser
     bool crnn_loaded = false;
     float* r0_wb = nullptr;      // w[9][32] (tap-major) b[32]
@@ -270,7 +271,7 @@ void weights_export(bbocr_ctx* c, void* dev_dst, size_t bytes);
 void weights_import(bbocr_ctx* c, const void* dev_src, size_t bytes);
 void load_craft(bbocr_ctx* c, const TensorMap& tm);
 void load_crnn(bbocr_ctx* c, const TensorMap& tm);
-void launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a);
+hipError_t launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a, bool may_decline = false);   // may_decline: hipErrorNotSupported is returned, not thrown
 void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, void* out, int out_cs, int cout_store, bool out_f32, const Act* addup = nullptr);
 void prof_collect(bbocr_ctx* c);
 Act conv_act(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const Act* a1, bool relu1, bool relu_out, int store);

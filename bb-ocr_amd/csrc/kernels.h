@@ -27,6 +27,9 @@ struct ConvArgs {
     const float* tail;     // non-null: fuse the CRAFT classifier tail (two 1x1 convs on 16 channels) into the epilogue (BN=64 config,
                            // cout_store 16): {b1[16], w2[32], b2[2]}; tail_frag: W1 as a bf16 MFMA A fragment [64 lanes][8]
     const uint16_t* tail_frag;
+    // post_w: a 1x1 conv 64 -> 64 (no bias, no ReLU) applied to the finished 64 output channels in the epilogue, packed by
+    // pack_post1x1_weights; only the product is stored (CRAFT: z = W_y u3b behind upconv3's 3x3, launch_conv declines other shapes)
+    const uint16_t* post_w;
     int sub;               // > 1: dilated 3x3 run as sub*sub plain convs on the phase sub-lattices (set by launch_conv)
     int stack;             // sub > 1: rows of one phase image; the sub*sub images of a page are stacked along y, one zero row apart
     const void* zero;      // >= 16 zero bytes in device memory (source of padding pixels for the LDS-DMA staged variant)
@@ -74,6 +77,7 @@ hipError_t launch_conv(const ConvPlan& p, ConvArgs a, hipStream_t s);   // a.zer
 hipError_t launch_up4_fused(const ConvPlan& p1, const ConvPlan& p3, ConvArgs a, hipStream_t s);
 
 // ------------------------------------------------------------------ detector front/back (craft_misc.hip)
+void pack_post1x1_weights(const float* w /*[64][64] cout x cin*/, uint16_t* out /*[2][4][64][8]*/, int el);
 void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_t* out /*[4][64][8]*/, int el);   // one k-step: taps 2g, 2g+1 per lane group, tap 8 in the pad slots; couts in the conv epilogue's run order
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);

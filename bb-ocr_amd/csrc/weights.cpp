@@ -79,7 +79,7 @@ static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int 
 
 // 1x1 conv over a channel concat [y (Cy) | skip (Cs)], BN folded, split into the two column blocks
 static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, ConvPlan& ps, const std::string& conv, const std::string& bn, int Cy,
-                           int Cs, int Cout) {
+                           int Cs, int Cout, std::vector<float>* wy_out = nullptr) {
     std::vector<float> w, b;
     fold_conv(tm, conv, bn, Cout, Cy + Cs, 1, w, b);
     std::vector<float> wy((size_t)Cout * Cy), ws((size_t)Cout * Cs), zero(Cout, 0.f);
@@ -87,6 +87,7 @@ static void load_split_1x1(bbocr_ctx* c, const TensorMap& tm, ConvPlan& py, Conv
         std::copy(w.begin() + (size_t)o * (Cy + Cs), w.begin() + (size_t)o * (Cy + Cs) + Cy, wy.begin() + (size_t)o * Cy);
         std::copy(w.begin() + (size_t)o * (Cy + Cs) + Cy, w.begin() + (size_t)(o + 1) * (Cy + Cs), ws.begin() + (size_t)o * Cs);
     }
+    if (wy_out) *wy_out = wy;
     py = make_plan(Cy, Cout, 1, 1, 0, 1, det_el(c));
     upload_plan(c, py, wy, zero);
     ps = make_plan(Cs, Cout, 1, 1, 0, 1, det_el(c));
@@ -208,7 +209,13 @@ void load_craft(bbocr_ctx* c, const TensorMap& tm) {
     load_layer(c, tm, c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1, det_el(c));
     load_split_1x1(c, tm, c->up3y, c->up3s, "upconv3.conv.0", "upconv3.conv.1", 128, 256, 128);
     load_layer(c, tm, c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1, det_el(c));
-    load_split_1x1(c, tm, c->up4y, c->up4s, "upconv4.conv.0", "upconv4.conv.1", 64, 128, 64);
+    {
+        std::vector<float> wy;
+        load_split_1x1(c, tm, c->up4y, c->up4s, "upconv4.conv.0", "upconv4.conv.1", 64, 128, 64, &wy);
+        std::vector<uint16_t> pk(2 * 4 * 64 * 8);
+        pack_post1x1_weights(wy.data(), pk.data(), det_el(c));      // z = W_y u3b in upconv3.3x3's epilogue (detector.cpp)
+        c->up4y_post = upload(c, pk);
+    }
     load_layer(c, tm, c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1, det_el(c));
     load_layer(c, tm, c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1, det_el(c));
     load_layer(c, tm, c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1, det_el(c));
