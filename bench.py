@@ -218,7 +218,7 @@ def main():
         traffic_src = (f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same detector, committed as profiles/{os.path.basename(pmc)} "
                        f"({t['read_MB_per_page']:.0f} MB read + {t['write_MB_per_page']:.0f} MB written per page), scaled to bytes per average launch")
     result["roofline"] = {
-        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel + conv3x3_up4_kernel + conv3x3_resw_kernel (all 26 detector launches of a pass: conv1_1+conv1_2 fused .. upconv4 fused .. conv_cls.4+tail)",
+        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel + conv3x3_up4_kernel + conv3x3_resw_kernel (every conv launch of the detector passes -- 25 per pass at this page size: conv1_1+conv1_2 fused .. upconv3.3x3 + upconv4.1x1(y) .. upconv4 fused .. conv_cls.4+tail)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
         "traffic": traffic, "traffic_source": traffic_src,
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
