@@ -632,24 +632,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_mfma_kernel(const ConvAr
 //   * every k-step ends with `s_waitcnt vmcnt(N)` + s_barrier where N (a compile-time constant per tap) is the number of
 //     operations issued after slice ks+1, so DMAs ride across RING-2 barriers and nothing ever drains to vmcnt(0).
 // vmcnt retires in order: a patch DMA issued at tap L has landed by the barrier of tap L+RING-1, hence the last one may be
-// issued at tap 9-RING.  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
+// issued at tap 9-RING (NTAP-RING in general).  ReLU-on-load (BN-terminated VGG slices) is applied to the B fragments after the LDS read.
 // FUSE1 (CRAFT conv1_2 only: Cin = 64, 16x16 tiles, BN = 64): the 64-channel input patch is not read from memory but PRODUCED
 // in the prologue from the uint8 RGB page -- normalizeMeanVariance + conv1_1 (3x3, 3->64) + BN + ReLU, one 27-deep (padded
 // to 32: a single k-step) MFMA product per 16 patch pixels -- and written straight into the two LDS patch buffers (both 32-channel chunks are
 // resident from the start, the k-loop issues no patch DMA).  The 157 MB/page conv1_1 activation never exists in HBM.
 // NF (cout fragments a wave multiplies, 4 or 2): layers with <= 32 real couts in a 64-cout tile (up4b, conv_cls.0/.2/.4) skip the two
 // fragments that are pure padding (couts 32..63 of the tile, see the cout mapping of the epilogue) -- half the MFMAs, same results.
-template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0, int KS = 3>
 __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const ConvArgs a) {
+    // KS = 3: 3x3 / padding 1 (nine taps per chunk); KS = 2: 2x2 / padding 0 (the CRNN's last conv: four taps per chunk)
+    constexpr int NTAP = KS * KS, PAD = KS == 3 ? 1 : 0;
+    static_assert((KS == 3 || KS == 2) && (KS == 3 || (!FUSE1 && EPI == 0)), "kernel size");
     constexpr int NW = WM * WN, NT = NW * 64, BN = WN * 64;
     static_assert(NW == 4, "one wave per 8-channel group of the patch");
     constexpr int WBUF = BN * 64, WPIECES = WBUF / 16, WPT = WPIECES / NT;
     static_assert(WPIECES % NT == 0 && (RING == 3 || RING == 4), "uniform DMA issue");
     // NPS: pixels per channel group in the LDS patch image; NPS < NPB*64 (exactly PH*PW) trims the patch to what the tile needs,
     // the last 64-pixel DMA block then runs with the lanes beyond NPS masked off
-    constexpr int NP = NPS, PSLOTS = 10 - RING;           // taps 0 .. 9-RING may issue patch DMAs
+    constexpr int NP = NPS, PSLOTS = NTAP + 1 - RING;     // taps 0 .. NTAP-RING may issue patch DMAs
+    constexpr int PPER = (NPB + PSLOTS - 1) / PSLOTS;     // patch DMA blocks per tap at most
     static_assert(NPS <= NPB * 64 && NPS > (NPB - 1) * 64 && NPS % 4 == 0, "patch size");
-    static_assert(NPB <= 2 * PSLOTS, "patch does not fit the DMA schedule");
+    static_assert(PSLOTS >= 1 && PPER * PSLOTS >= NPB, "patch does not fit the DMA schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wbuf = smem;                    // [RING][WBUF]
     unsigned char* const pbuf = smem + RING * WBUF;      // [2][NP*64]
@@ -660,7 +664,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int sub = a.sub;
-    const int nk = a.nchunks * 9;
+    const int nk = a.nchunks * NTAP;
     // the fused conv1_2 kernel always runs 16 x 16 tiles (18-pixel patch rows): compile-time, so that every fragment read of the k-loop is
     // one base register + an immediate offset
     const int fpr = FUSE1 ? 1 : a.TW >> 4;
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     const int pw_magic = (65536 + a.PW - 1) / a.PW;     // pix / PW == (pix * magic) >> 16 exactly for pix < 448, PW <= 66
     const int stack_magic = ((1 << 20) + a.stack) / (a.stack + 1);   // vy / (stack+1) == (vy * magic) >> 20 (launch_conv checks the exactness bound)
     auto geom_pix = [&](const Geo& g) {
-        const int iy0 = g.oy0 - 1, ix0 = g.ox0 - 1;
+        const int iy0 = g.oy0 - PAD, ix0 = g.ox0 - PAD;
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             const int pix = pb * 64 + lane;
@@ -749,26 +753,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 
     // patch DMA schedule inside a chunk: PCNT(tap) blocks at tap (first taps take two while NPB > PSLOTS)
     struct Sched {
-        static constexpr int pcnt(int tap) {
-            if (FUSE1) return 0;
-            return tap >= PSLOTS ? 0 : ((NPB - PSLOTS > tap ? 2 : 1) * (tap < (NPB > PSLOTS ? PSLOTS : NPB) ? 1 : 0));
+        static constexpr int pcnt(int tap) {       // the NPB blocks dealt over the first PSLOTS taps, the early taps take the larger shares
+            if (FUSE1 || tap >= PSLOTS) return 0;
+            const int base = NPB / PSLOTS, extra = NPB % PSLOTS;
+            return base + (tap < extra ? 1 : 0);
         }
         static constexpr int pfirst(int tap) { int s = 0; for (int t = 0; t < tap; ++t) s += pcnt(t); return s; }
-        static constexpr int wcnt(bool more, int tap) { return (more || tap < 9 - (RING - 1)) ? WPT : 0; }
+        static constexpr int wcnt(bool more, int tap) { return (more || tap < NTAP - (RING - 1)) ? WPT : 0; }
         // operations younger than slice ks+1 at the end of tap `tap` of a chunk of kind `more` (previous chunk: kind true)
         static constexpr int younger(bool more, int tap) {
             int nv = wcnt(more, tap) + (more ? pcnt(tap) : 0);
             for (int back = 1; back <= RING - 2; ++back) {
                 const int t = tap - back;
                 const bool m = t >= 0 ? more : true;
-                const int tt = t >= 0 ? t : t + 9;
+                const int tt = t >= 0 ? t : t + NTAP;
                 const int pc = m ? pcnt(tt) : 0;
                 nv += (back == RING - 2) ? pc : (wcnt(m, tt) + pc);   // the oldest k-step of the window: only what followed its slice
             }
             return nv;
         }
     };
-    static_assert(FUSE1 || Sched::pfirst(9) == NPB, "patch DMA schedule must cover the patch");
+    static_assert(FUSE1 || Sched::pfirst(NTAP) == NPB, "patch DMA schedule must cover the patch");
 
     // prologue: first RING-1 weight slices + the whole first patch of the first tile
 #pragma unroll
@@ -907,7 +912,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     auto step = [&](auto tap_c, auto more_c, int c) {
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool MORE = decltype(more_c)::value;
-        constexpr int ky = tap / 3, kx = tap % 3;
+        constexpr int ky = tap / KS, kx = tap % KS;
         const unsigned char* wb = wbuf + wslot * WBUF + lane_w_off;
         const unsigned char* pb = pbuf + par * patch_bytes + lane_patch_off + (ky * PW + kx) * 16;
         typename El<EL>::v8 af[NF], bq[MF];
@@ -929,11 +934,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
         if constexpr (MORE && Sched::pcnt(tap) > 0) {
             constexpr int p0 = Sched::pfirst(tap);
             const int nc = c + 1;
-            issue_p(spix[p0], nc, par ^ 1, std::integral_constant<int, p0>{});
-            if constexpr (Sched::pcnt(tap) > 1) issue_p(spix[p0 + 1], nc, par ^ 1, std::integral_constant<int, p0 + 1>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_p(spix[p0 + I], nc, par ^ 1, std::integral_constant<int, p0 + I>{}), ...); }(
+                std::make_integer_sequence<int, Sched::pcnt(tap)>{});
         }
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int kyn = (tap + 1) / 3, kxn = (tap + 1) % 3;
+        constexpr int kyn = (tap + 1) / KS, kxn = (tap + 1) % KS;
         const unsigned char* pbn = pbuf + par * patch_bytes + lane_patch_off + (kyn * PW + kxn) * 16;
 #pragma unroll
         for (int g = 0; g < MF / 2; ++g) {
@@ -945,7 +950,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
             for (int f = 2 * g + 4; f < 2 * g + 6; ++f) {
                 if (f < MF) bq[f] = *(const typename El<EL>::v8*)(pb + frag_off[f]);
-                else if constexpr (tap < 8) pre[f - MF] = *(const typename El<EL>::v8*)(pbn + frag_off[f - MF]);
+                else if constexpr (tap < NTAP - 1) pre[f - MF] = *(const typename El<EL>::v8*)(pbn + frag_off[f - MF]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -971,7 +976,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
     };
     auto chunk = [&](auto more_c, int c) {
         relu_patch(c);
-        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, 9>{});
+        [&]<int... T>(std::integer_sequence<int, T...>) { (step(std::integral_constant<int, T>{}, more_c, c), ...); }(std::make_integer_sequence<int, NTAP>{});
         par ^= 1;
     };
     for (int c = 0; c + 1 < a.nchunks; ++c) chunk(std::true_type{}, c);
@@ -1535,9 +1540,9 @@ static const char* conv_stamps_dir() {
 #endif
 }
 
-template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0>
+template <int EL, int WM, int WN, int MF, int NPB, int RING, int NPS = NPB * 64, bool FUSE1 = false, int NF = 4, int EPI = 0, int KS = 3>
 static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
-    auto k = conv3x3_dma_kernel<EL, WM, WN, MF, NPB, RING, NPS, FUSE1, NF, EPI>;
+    auto k = conv3x3_dma_kernel<EL, WM, WN, MF, NPB, RING, NPS, FUSE1, NF, EPI, KS>;
     const size_t smem_max = (size_t)RING * WN * 64 * 64 + (size_t)2 * NPS * 64;
     // a single 32-channel chunk (conv_cls: Cin = 32) never touches the second patch buffer: without it a workgroup needs 33 KB and
     // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
@@ -1666,8 +1671,13 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
     }
     const int ring = 2;
     const int max_piter = 16;
+    // 2x2 / padding 0 (the CRNN's last conv, 4 input rows -> 3) on the LDS-DMA kernel: 4 x 64 tiles, whose 5 x 65 patch is six 64-pixel blocks
+    const bool dma2x2 = conv_dma() && a.zero && p.KH == 2 && p.KW == 2 && p.dil == 1 && p.pad_h == 0 && p.pad_w == 0 && !a.pool_mode && !a.tail &&
+                        !a.addup && !a.post_w && (BN == 128 || BN == 64);
     // tile shape: the TH x (BM/TH) rectangle with the least (MFMA work on partial tiles + patch staging) per layer
-    {
+    if (dma2x2) {
+        a.TH = 4; a.TW = 64; a.PH = 5; a.PW = 65; a.NP = 384;
+    } else {
         long long best = -1;
         for (int th = 16; th >= 4; th >>= 1) {
             const int tw = BM / th;
@@ -1705,6 +1715,8 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
         return hipErrorInvalidValue;
     if (conv_dma() && p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && a.zero && !a.pool_mode)
         return BN == 256 ? launch_dma1x1<EL, 2, 4, 8>(a, s) : (BN == 128 ? launch_dma1x1<EL, 2, 2, 8>(a, s) : launch_dma1x1<EL, 4, 1, 4>(a, s));
+    if (dma2x2)
+        return BN == 128 ? launch_dma_one<EL, 2, 2, 8, 6, 4, 384, false, 4, 0, 2>(a, grid, s) : launch_dma_one<EL, 4, 1, 4, 6, 3, 384, false, 4, 0, 2>(a, grid, s);
     if (conv_dma() && p.KH == 3 && p.KW == 3 && p.dil == 1 && p.pad_h == 1 && p.pad_w == 1 && a.zero) {
         const int npb = cdiv(a.PH * a.PW, 64);
         if (npb == 6 || npb == 7) {

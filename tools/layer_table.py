@@ -16,7 +16,8 @@ for r in rows[start:]:
         name, m = MACS[k]; k += 1
         if 'conv3x3_up4' in n:          # upconv4's 1x1 over s1 and its 3x3 in one launch
             name, m = 'up4s+b', m + MACS[k][1]; k += 1
-        if name == 'up3b' and n.rstrip().endswith(', 1>(ConvArgs)'):      # upconv4's 1x1 over u3b applied in upconv3.3x3's epilogue (EPI = 1)
+        targs = n[n.find('<') + 1:n.find('>')].split(', ')
+        if name == 'up3b' and 'conv3x3_dma' in n and len(targs) > 9 and targs[9] == '1':      # upconv4's 1x1 over u3b applied in upconv3.3x3's epilogue (EPI = 1)
             name, m = 'up3b+4y', m + MACS[k][1]; k += 1
         print(f"{name:8s} {n[n.find('<'):n.find('>')+1]:24s} {d:9.1f} us {m*npages*2/(d*1e-6)/1e3:8.1f} TFLOP/s  grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']}")
         tot += d

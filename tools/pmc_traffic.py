@@ -25,7 +25,7 @@ names = ["conv1_2(+conv1_1)", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3
          "up1b", "up2y", "up2s", "up2b", "up3y", "up3s", "up3b", "up4y", "up4s", "up4b", "cls0", "cls2", "cls4(+tail)"]
 if any("conv3x3_up4" in kn for kn, _ in F):      # upconv4 fused: one launch for the 1x1 over s1 and the 3x3
     names = names[:22] + ["up4s+up4b (fused)"] + names[24:]
-if any("conv3x3_dma" in kn and kn.count(",") == 9 and kn.rstrip().endswith(", 1>") for kn, _ in F):      # upconv4's y-half 1x1 applied in upconv3.3x3's epilogue
+if any("conv3x3_dma" in kn and len(kn[kn.find("<") + 1:kn.find(">")].split(", ")) > 9 and kn[kn.find("<") + 1:kn.find(">")].split(", ")[9] == "1" for kn, _ in F):      # upconv4's y-half 1x1 applied in upconv3.3x3's epilogue
     i = names.index("up3b")
     names = names[:i] + ["up3b+up4y (fused)"] + names[i + 2:]
 layers = []
