@@ -1004,10 +1004,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 // loads the NF = 2 real cout fragments of every (chunk, tap) slice ONCE (2 KB each, 18-36 KB in all) and then walks tiles
 // tile0 + i * gridDim.x: per tile only the 18x18 activation patch is DMA'd (the next tile's while this one is multiplied when DB),
 // the k-loop reads weights and patch from LDS without a single barrier, and the shared epilogue stores.  Two barriers per tile.
-template <int EL, int NCH, bool DB>
+template <int EL, int NCH, bool DB, int NF = 2, bool LEAN = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) {
-    constexpr int MF = 4, NF = 2, NP = 324, NPB = 6, NK = NCH * 9;
-    constexpr int WSL = NF * 1024;                       // resident bytes per (chunk, tap) slice: fragments 0 and 1 of the 4 KB slice
+    // NF = 2: the <= 32-cout layers (fragments 0 and 1 of every slice are resident); NF = 4, LEAN: a 64-cout layer with one input chunk whose
+    // 2x2 max-pool is fused and only the pooled tensor kept (the CRNN's 32 -> 64 layer: nine 4 KB slices resident, conv_epilogue_pool2x2_lean)
+    static_assert(NF == 2 || (NF == 4 && NCH == 1), "resident weights");
+    constexpr int MF = 4, NP = 324, NPB = 6, NK = NCH * 9;
+    constexpr int WSL = NF * 1024;                       // resident bytes per (chunk, tap) slice
     constexpr int PCH = NP * 64;                         // patch bytes per chunk
     constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1020,12 +1023,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) 
     // resident weights: NK slices x 2 KB, 4 KB per workgroup-wide DMA instruction (two slices)
     {
         const unsigned char* wsrc = (const unsigned char*)a.wpk;
+        if constexpr (NF == 4) {
 #pragma unroll
-        for (int k2 = 0; k2 < (NK + 1) / 2; ++k2) {
-            const int ks = k2 * 2 + (tid >> 7);          // threads 0..127 -> slice 2*k2, 128..255 -> slice 2*k2 + 1
-            if (ks < NK)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16),
-                                                 (__attribute__((address_space(3))) void*)(wres + (k2 * 2 + (wave >> 1)) * WSL + (wave & 1) * 1024), 16, 0, 0);
+            for (int ks = 0; ks < NK; ++ks)              // a whole 4 KB slice per workgroup-wide DMA instruction
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)tid * 16),
+                                                 (__attribute__((address_space(3))) void*)(wres + ks * WSL + wave * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < (NK + 1) / 2; ++k2) {
+                const int ks = k2 * 2 + (tid >> 7);          // threads 0..127 -> slice 2*k2, 128..255 -> slice 2*k2 + 1
+                if (ks < NK)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)ks * 4096 + (size_t)(tid & 127) * 16),
+                                                     (__attribute__((address_space(3))) void*)(wres + (k2 * 2 + (wave >> 1)) * WSL + (wave & 1) * 1024), 16, 0, 0);
+            }
         }
     }
     const int pw_magic = (65536 + 18 - 1) / 18;
@@ -1115,7 +1125,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) 
             asm volatile("s_barrier" ::: "memory");
             if (next < ntiles) issue_patch(next, 0);
         }
-        conv_epilogue<EL, MF>(a, acc, n, 0, ty * 16, tx * 16, wm, 0, 1, lane, 64);
+        if constexpr (LEAN) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, n, ty * 16, tx * 16, wm, lane);
+        else conv_epilogue<EL, MF>(a, acc, n, 0, ty * 16, tx * 16, wm, 0, 1, lane, 64);
         if constexpr (DB) buf ^= 1;
     }
 }
@@ -1142,7 +1153,8 @@ static hipError_t launch_resw(const ConvArgs& a, hipStream_t s) {
         return hipGetLastError();
     };
     constexpr size_t P = 324 * 64, W1 = 9 * 2048, W2 = 18 * 2048;
-    static bool at[4] = {false, false, false, false};
+    static bool at[5] = {false, false, false, false, false};
+    if (a.cout_store == 64) return go(conv3x3_resw_kernel<EL, 1, true, 4, true>, 9 * 4096 + 2 * P, 2, at[4]);       // 78.3 KB: two workgroups per CU
     if (a.nchunks == 1) {
         if (db_knob) return go(conv3x3_resw_kernel<EL, 1, true>, W1 + 2 * P, 2, at[0]);          // 59.9 KB: two workgroups per CU
         return go(conv3x3_resw_kernel<EL, 1, false>, W1 + P, 4, at[1]);                           // 39.2 KB: four
@@ -1605,6 +1617,11 @@ static hipError_t launch_dma(const ConvArgs& a, int npb, int grid, hipStream_t s
             static const bool half = (diag_knob("BBOCR_CONV_NF2", 1) != 0);   // A/B knob
             static const bool resw = (diag_knob("BBOCR_CONV_RESW", 1) != 0);    // A/B knob
             if (resw && half && a.cout_store <= 32 && a.nchunks <= 2 && a.sub == 1 && !a.C1 && !a.pool_mode && a.TH == 16 && a.TW == 16 && a.ntiles_n == 1)
+                return launch_resw<EL>(a, s);
+            // one input chunk, 64 couts, MaxPool2d(2,2) fused and only the pooled tensor kept (the CRNN's 32 -> 64 layer): nine 4 KB slices resident
+            static const bool resw64 = (diag_knob("BBOCR_CONV_RESW64", 1) != 0);    // A/B knob
+            if (resw && resw64 && a.cout_store == 64 && a.nchunks == 1 && a.sub == 1 && !a.C1 && a.pool_mode == 1 && !a.store_full && !a.split_off && !a.out_f32 &&
+                !a.tail && !a.relu_in0 && a.TH == 16 && a.TW == 16 && a.ntiles_n == 1 && a.acc_scale > 0.f)
                 return launch_resw<EL>(a, s);
             if (half && a.cout_store <= 32) return launch_dma_one<EL, WM, WN, MF, 6, 3, 324, false, 2>(a, grid, s);
             return launch_dma_one<EL, WM, WN, MF, 6, 3, 324>(a, grid, s);
