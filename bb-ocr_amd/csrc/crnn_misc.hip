@@ -321,9 +321,110 @@ __global__ void __launch_bounds__(256) crnn_conv0_kernel(const uint16_t* __restr
     }
 }
 
-hipError_t launch_crnn_conv0(const uint16_t* in, const float* w, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s) {
+// The same layer on the MFMA pipe (bf16 / fp16 modes): the VALU kernel above runs at the packed-fp32 issue rate (v_pk_fma_f32 issues at half
+// rate: 2,900 of them per wave), while the 9-tap x 32-channel product is a 16-cout x 16-pixel x K MFMA with K to spare.  The input pixels are
+// element-type values already (crop_final rounds them); the fp32 weights are split THREE ways into element-type terms w = hi + lo + lo2
+// (24+ significand bits), so every product is exact in fp32 and the result differs from the FMA chain only by the order of fp32 additions:
+//   K = 32: lane group 0 / 1 / 2 = taps 0..7 x (hi / lo / lo2), group 3 unused (zero weights); tap 8 is one fp32 FMA per output value.
+// B fragment of a 16-pixel row segment: 8 two-byte LDS reads per lane at compile-time offsets from the lane's pixel, the same for every lane.
+// A wave owns row PAIRS (2r, 2r+1): the 2x2 pool is one v_max3 across the pair's two fragments (with the ReLU floor) and one DPP max across
+// neighbouring pixels; a lane's 8 pooled values are 8 consecutive channels = one 16-byte store.
+void pack_crnn_conv0_mfma(const float* w_tap_major, uint16_t* out, int el) {
+    size_t o = 0;
+    for (int j = 0; j < 2; ++j)
+        for (int l = 0; l < 64; ++l) {
+            const int m = l & 15, kg = l >> 4;
+            const int cout = 8 * (m >> 2) + 4 * j + (m & 3);     // D row 4g + r of fragment j <-> channel 8g + 4j + r
+            for (int t = 0; t < 8; ++t) {
+                const float v = w_tap_major[t * 32 + cout];
+                const float hi = el_to_f32_host(el, f32_to_el_host(el, v));
+                const float lo = el_to_f32_host(el, f32_to_el_host(el, v - hi));
+                const float lo2 = el_to_f32_host(el, f32_to_el_host(el, (v - hi) - lo));
+                out[o++] = f32_to_el_host(el, kg == 0 ? hi : (kg == 1 ? lo : (kg == 2 ? lo2 : 0.f)));
+            }
+        }
+}
+
+template <int EL>
+__global__ void __launch_bounds__(256) crnn_conv0_mfma_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ afrag, const float* __restrict__ w,
+                                                              const float* __restrict__ b, uint16_t* __restrict__ out, int W) {
+    constexpr int TW = 64, PITCH = TW + 16, ROWS = 66;            // LDS tile: rows -1 .. 64, columns x0 - 8 .. x0 + 71 (16-byte chunks)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[ROWS * PITCH];
+    typedef typename El<EL>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int x0 = blockIdx.x * TW, img = blockIdx.y;
+    const int OW = W >> 1;
+    const uint16_t* src = in + (size_t)img * 64 * W;
+    for (int idx = tid; idx < ROWS * (PITCH / 4); idx += 256) {
+        const int row = idx / (PITCH / 4), ch = idx - row * (PITCH / 4);
+        const int iy = row - 1, ix = x0 - 8 + ch * 4;
+        u32x2 v = {0u, 0u};
+        if (iy >= 0 && iy < 64 && ix >= 0 && ix + 4 <= W) v = *(const u32x2*)(src + (size_t)iy * W + ix);      // (W % 4 == 0: whole 8-byte chunks only)
+        *(u32x2*)(tile + row * PITCH + ch * 4) = v;
+    }
+    const v8 a0 = *(const v8*)(afrag + (size_t)lane * 8), a1 = *(const v8*)(afrag + (size_t)(64 + lane) * 8);
+    float w8[8], bi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w8[i] = w[8 * 32 + 8 * g + i];
+        bi[i] = b[8 * g + i];
+    }
+    __syncthreads();
+    auto frag = [&](int y, int cf, f32x4& d0, f32x4& d1) {
+        const uint16_t* p = tile + (y + 1) * PITCH + 8 + cf * 16 + n;       // the lane's pixel
+        u32x4 bq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t0 = 2 * i, t1 = 2 * i + 1;
+            const unsigned int lo = p[(t0 / 3 - 1) * PITCH + (t0 % 3 - 1)], hi = p[(t1 / 3 - 1) * PITCH + (t1 % 3 - 1)];
+            bq[i] = lo | (hi << 16);
+        }
+        const float x8 = El<EL>::to_f32(p[PITCH + 1]);
+        d0 = El<EL>::mfma(a0, __builtin_bit_cast(v8, bq), (f32x4){bi[0], bi[1], bi[2], bi[3]});
+        d1 = El<EL>::mfma(a1, __builtin_bit_cast(v8, bq), (f32x4){bi[4], bi[5], bi[6], bi[7]});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d0[r] = fmaf(w8[r], x8, d0[r]);
+            d1[r] = fmaf(w8[4 + r], x8, d1[r]);
+        }
+    };
+#pragma unroll 1
+    for (int rp = 0; rp < 8; ++rp) {
+        const int y = 2 * (wave * 8 + rp);
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+            f32x4 u0, u1, l0, l1;
+            frag(y, cf, u0, u1);
+            frag(y + 1, cf, l0, l1);
+            float m[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                m[r] = __builtin_fmaxf(__builtin_fmaxf(u0[r], l0[r]), 0.f);          // v_max3: the row pair and the ReLU floor
+                m[4 + r] = __builtin_fmaxf(__builtin_fmaxf(u1[r], l1[r]), 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[i]), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true)));
+            const int px = (x0 + cf * 16 + n) >> 1;
+            if (!(n & 1) && px < OW) {
+                const u32x4 o = {El<EL>::pack2(m[0], m[1]), El<EL>::pack2(m[2], m[3]), El<EL>::pack2(m[4], m[5]), El<EL>::pack2(m[6], m[7])};
+                *(u32x4*)(out + (((size_t)img * 32 + (y >> 1)) * OW + px) * 32 + 8 * g) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s,
+                             const uint16_t* afrag) {
     const size_t total = (size_t)n * 32 * (W / 2);
     if (total == 0) return hipSuccess;
+    if (afrag && mode != REC_SPLIT && (W & 3) == 0 && n <= 65535) {
+        const dim3 grid((W + 63) / 64, n);
+        if (mode == REC_F16) hipLaunchKernelGGL(crnn_conv0_mfma_kernel<1>, grid, dim3(256), 0, s, in, afrag, w, b, out, W);
+        else hipLaunchKernelGGL(crnn_conv0_mfma_kernel<0>, grid, dim3(256), 0, s, in, afrag, w, b, out, W);
+        return hipGetLastError();
+    }
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (mode == REC_SPLIT) hipLaunchKernelGGL(crnn_conv0_kernel<REC_SPLIT>, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);
     else if (mode == REC_F16) hipLaunchKernelGGL(crnn_conv0_kernel<REC_F16>, dim3(grid), dim3(256), 0, s, in, w, b, out, n, W);

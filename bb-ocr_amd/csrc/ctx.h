@@ -148,6 +148,7 @@ struct bbocr_ctx {
     // ---- recogniser
     bool crnn_loaded = false;
     float* r0_wb = nullptr;      // w[9][32] (tap-major) b[32]
+    uint16_t* r0_afrag = nullptr;  // taps 0..7 three-way split into element-type terms, as MFMA A fragments (crnn_conv0_mfma_kernel)
     ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
     uint16_t* whh[2] = {nullptr, nullptr};
     float whh_scale[2] = {1.f, 1.f};   // exact mode: 2^-s of the packed W_hh (pack_lstm_whh_split)

@@ -119,7 +119,9 @@ hipError_t launch_crops(const uint8_t* gray, int H, int W, const CropDesc* descs
 enum { REC_BF16 = 0, REC_F16 = 1, REC_SPLIT = 2 };
 constexpr float SPLIT_LO_SCALE = 2048.f;
 hipError_t launch_crop_hist(const uint8_t* scratch, const CropDesc* descs_dev, int first, int count, unsigned int* hist, hipStream_t s);
-hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[32][9]*/, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s);
+hipError_t launch_crnn_conv0(const uint16_t* in, const float* w /*[9][32] tap-major*/, const float* b, uint16_t* out, int n, int W, int mode, hipStream_t s,
+                             const uint16_t* afrag = nullptr /*pack_crnn_conv0_mfma: the MFMA form (bf16 / fp16 modes, W % 4 == 0)*/);
+void pack_crnn_conv0_mfma(const float* w_tap_major /*[9][32]*/, uint16_t* out /*[2][64][8]*/, int el);
 hipError_t launch_rowmean3(const uint16_t* in, uint16_t* out, int n, int T, int C, int mode, hipStream_t s);   // C: logical channels
 // wide recogniser image (all crops side by side, CropDesc::slot = first column, ::pad_ = first pooled row): clear the separator
 // columns of a layer output [H][Wl][C] (shift = log2 horizontal down-scale), and the 3-row mean gathered into the pooled rows

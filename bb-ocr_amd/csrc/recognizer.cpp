@@ -72,7 +72,7 @@ void crnn_features(bbocr_ctx* c, const uint16_t* crops, int n, int imgW, uint16_
     const int T = imgW / 4 - 1;
     const int m = rec_mul(c);
     Act c0{ar.alloc<uint16_t>((size_t)n * 32 * (imgW / 2) * 32 * m), n, 32, imgW / 2, 32 * m};
-    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, rec_mode(c), c->cur));
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(crops, c->r0_wb, c->r0_wb + 288, c0.p, n, imgW, rec_mode(c), c->cur, c->r0_afrag));
     Act q1 = conv_pool_act(c, c->r1, c0, false, true, 64, 1, false, nullptr);
     Act c2 = conv_act(c, c->r2, q1, false, nullptr, false, true, 128);
     Act q2 = conv_pool_act(c, c->r3, c2, false, true, 128, 2, false, nullptr);
@@ -91,7 +91,7 @@ static void crnn_features_wide(bbocr_ctx* c, const uint16_t* wide, int Wt, const
     c->prof_group = 1;
     const int m = rec_mul(c);
     Act c0{ar.alloc<uint16_t>((size_t)32 * (Wt / 2) * 32 * m), 1, 32, Wt / 2, 32 * m};
-    if (!ar.dry) HIPCHK(launch_crnn_conv0(wide, c->r0_wb, c->r0_wb + 288, c0.p, 1, Wt, rec_mode(c), c->cur));
+    if (!ar.dry) HIPCHK(launch_crnn_conv0(wide, c->r0_wb, c->r0_wb + 288, c0.p, 1, Wt, rec_mode(c), c->cur, c->r0_afrag));
     auto gaps = [&](const Act& a, int shift) {
         if (!ar.dry) HIPCHK(launch_crnn_zero_gaps(a.p, descs, first, count, a.H, a.W, a.C, shift, c->cur));
     };

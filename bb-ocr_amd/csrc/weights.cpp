@@ -251,6 +251,11 @@ void load_crnn(bbocr_ctx* c, const TensorMap& tm) {
             for (int tap = 0; tap < 9; ++tap) t[tap * 32 + co] = w[co * 9 + tap];
         std::copy(b, b + 32, t.begin() + 288);
         c->r0_wb = upload(c, t);
+        if (!rec_split(c)) {
+            std::vector<uint16_t> af(2 * 64 * 8);
+            pack_crnn_conv0_mfma(t.data(), af.data(), rec_el(c));
+            c->r0_afrag = upload(c, af);
+        }
     }
     load_layer(c, tm, c->r1, fe + "3", "", 32, 64, 3, 1, 1, rec_el(c), rec_split(c));
     load_layer(c, tm, c->r2, fe + "6", "", 64, 128, 3, 1, 1, rec_el(c), rec_split(c));
