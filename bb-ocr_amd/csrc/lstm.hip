@@ -37,11 +37,21 @@ __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_
 //   h fragments are read one kk ahead (2 x 4 registers instead of all eight), x_t is loaded at the top of its own step.
 // Packed layout [dir][wave 8][v 64][lane 64][8]; input-projection channels permuted so that a lane's 8 gate
 // pre-activations of one sequence are 16 contiguous bytes (lstm8_xproj_channel).
+#ifndef LSTM8_S0
 #define LSTM8_S0 10     // streamed fragments held at the top of a step
+#endif
+#ifndef LSTM8_NR
 #define LSTM8_NR 28
+#endif
+#ifndef LSTM8_S1
 #define LSTM8_S1 8      // streamed fragments fetched while the first ones are consumed
+#endif
+#ifndef LSTM8_NL
 #define LSTM8_NL 18
+#endif
+#ifndef LSTM8_LD
 #define LSTM8_LD 8      // LDS read-ahead (fragments); the ring reuses the registers of the (by then consumed) streamed buffer
+#endif
 void pack_lstm_whh8(const float* whh_fwd, const float* whh_bwd, uint16_t* out, int el) {
     size_t o = 0;
     for (int d = 0; d < 2; ++d) {
