@@ -37,6 +37,12 @@ __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_
 //   h fragments are read one kk ahead (2 x 4 registers instead of all eight), x_t is loaded at the top of its own step.
 // Packed layout [dir][wave 8][v 64][lane 64][8]; input-projection channels permuted so that a lane's 8 gate
 // pre-activations of one sequence are 16 contiguous bytes (lstm8_xproj_channel).
+// LSTM8_ABL: timing-only ablations of lstm8_kernel (garbage results; variant builds for tools/lstm_abl.sh only): 1 no transcendentals in the gate
+// math, 2 no L2-streamed weight fragments, 4 no LDS weight reads, 8 no x loads, 16 no output store.  Measured (2,048 sequences, T = 255, 887 us):
+// -5 / -11 / -3 / -15 / -11 %, all five together -46 %: no single term bounds a step, the memory side as a whole is a third of it.
+#ifndef LSTM8_ABL
+#define LSTM8_ABL 0
+#endif
 #ifndef LSTM8_S0
 #define LSTM8_S0 10     // streamed fragments held at the top of a step
 #endif
@@ -115,7 +121,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         gfrag_ptr wv = wv0;
         asm volatile("" : "+v"(wv));  // keep these loads inside the time loop (they would otherwise be hoisted and spilled)
 #pragma unroll
-        for (int i = 0; i < LSTM8_S0; ++i) sb[i] = wv[(size_t)i * 64];
+        for (int i = 0; i < LSTM8_S0; ++i) sb[i] = (LSTM8_ABL & 2) ? wreg[i] : wv[(size_t)i * 64];
     };
     stream_head();
     __syncthreads();
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         const int t = dir ? (T - 1 - step) : step;
         u32x4 xq[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xq[r] = *(const u32x4*)(xproj + xrow[r] + (size_t)t * 2048);
+        for (int r = 0; r < 4; ++r) xq[r] = (LSTM8_ABL & 8) ? (u32x4){0u, 0u, 0u, 0u} : *(const u32x4*)(xproj + xrow[r] + (size_t)t * 2048);
         const unsigned char* hb = hbuf[cur] + (g * 16 + u) * 16;
         unsigned char* hn = hbuf[cur ^ 1];
         gfrag_ptr wv = wv0;
@@ -146,9 +152,9 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
             else if constexpr (v < L0) w = sb[v - S1];
             else w = lb[(v - L0) % LSTM8_LD];
             acc[a][q] = El<EL>::mfma(af[kk & 1], w, acc[a][q]);
-            if constexpr (v < LSTM8_S1) sb[v] = wv[(size_t)(S1 + v) * 64];      // the buffer slot is free again: late fragment v
+            if constexpr (v < LSTM8_S1) sb[v] = (LSTM8_ABL & 2) ? wreg[v] : wv[(size_t)(S1 + v) * 64];      // the buffer slot is free again: late fragment v
             // LDS read-ahead: fragment v+LD goes into the ring slot fragment v just left (the first LD reads fill the empty ring)
-            if constexpr (v + LSTM8_LD >= L0 && v + LSTM8_LD < 64) lb[(v + LSTM8_LD - L0) % LSTM8_LD] = wl[(size_t)(v + LSTM8_LD - L0) * 64];
+            if constexpr (v + LSTM8_LD >= L0 && v + LSTM8_LD < 64) lb[(v + LSTM8_LD - L0) % LSTM8_LD] = (LSTM8_ABL & 4) ? wreg[(v + LSTM8_LD - L0) % LSTM8_NR] : wl[(size_t)(v + LSTM8_LD - L0) * 64];
             // hipcc sinks loads towards their use to save registers, which would put the L2 latency back in front of the MFMA:
             // nothing may be scheduled across the end of the refill block
             if constexpr (v == LSTM8_S1 - 1 || v >= L0 - LSTM8_LD - 1) __builtin_amdgcn_sched_barrier(0);   // (and the LDS read-ahead distance)
@@ -165,8 +171,8 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
             auto ex2 = [](f32x2_t x) { return (f32x2_t){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; };
             auto rcp2 = [](f32x2_t x) { return (f32x2_t){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; };
             const f32x2_t one = {1.f, 1.f}, nl = {-1.442695041f, -1.442695041f}, l2 = {2.885390082f, 2.885390082f}, m2 = {-2.f, -2.f};
-            auto sig2 = [&](f32x2_t x) { return rcp2(one + ex2(x * nl)); };
-            auto tanh2 = [&](f32x2_t x) { return __builtin_elementwise_fma(rcp2(one + ex2(x * l2)), m2, one); };   // 1 - 2/(1+e^{2x}), exact fma
+            auto sig2 = [&](f32x2_t x) { if constexpr ((LSTM8_ABL & 1) != 0) return x * nl; else return rcp2(one + ex2(x * nl)); };
+            auto tanh2 = [&](f32x2_t x) { if constexpr ((LSTM8_ABL & 1) != 0) return x * l2; else return __builtin_elementwise_fma(rcp2(one + ex2(x * l2)), m2, one); };   // 1 - 2/(1+e^{2x}), exact fma
 #pragma unroll
             for (int rp = 0; rp < 4; rp += 2) {
                 const unsigned int a0 = xq[rp][a * 2], a1 = xq[rp][a * 2 + 1], b0 = xq[rp + 1][a * 2], b1 = xq[rp + 1][a * 2 + 1];
@@ -189,7 +195,7 @@ __global__ void __launch_bounds__(512, 2) lstm8_kernel(const uint16_t* __restric
         gate_group(std::integral_constant<int, 1>{});
         asm volatile("" ::"v"(pf));
         __syncthreads();
-        if (wb_seq < n) {
+        if (wb_seq < n && !(LSTM8_ABL & 16)) {
             const u32x4 h0 = *(const u32x4*)(hn + (wb_kg * 16 + wb_seq) * 16);
             *(u32x4*)(out + ((size_t)row0 + (size_t)wb_seq * T + t) * 512 + dir * 256 + wb_kg * 8) = h0;
         }
