@@ -17,7 +17,7 @@ class bbocr_config(C.Structure):
     _fields_ = [("device", C.c_int), ("det_sub_batch", C.c_int), ("rec_max_cols", C.c_int), ("precision", C.c_int), ("reserved", C.c_int * 4)]
 
 
-PRECISIONS = {"bf16": 0, "fp16": 1, "exact": 2}
+PRECISIONS = {"bf16": 0, "fp16": 1, "exact": 2, "mixed": 3}
 
 
 class bbocr_tensor_desc(C.Structure):

@@ -19,6 +19,10 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
     try {
         c = new bbocr_ctx();
         if (cfg) c->cfg = *cfg;
+        if (c->cfg.precision < BBOCR_PREC_BF16 || c->cfg.precision > BBOCR_PREC_MIXED) {
+            delete c;                      // an unknown value must not silently mean one of the modes
+            return BBOCR_ERR_ARG;
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->cfg.device < 0 || c->cfg.device >= ndev) {
             delete c;
@@ -66,6 +70,8 @@ const char* bbocr_last_error(bbocr_ctx* c) { return c ? c->err.c_str() : "null c
 int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n) {
     return guarded(ctx, [&] {
         if (!descs || n <= 0 || (which != 0 && which != 1)) fail(BBOCR_ERR_ARG, "bad weight descriptor table");
+        if (which == 0 ? ctx->craft_loaded : ctx->crnn_loaded)
+            fail(BBOCR_ERR_STATE, "this network is already loaded: the packed blocks (and the weight blob layout) are fixed per context -- create a new context");
         TensorMap tm(descs, n);
         if (which == 0) load_craft(ctx, tm);
         else load_crnn(ctx, tm);
@@ -75,6 +81,8 @@ int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs
 int bbocr_alloc_weights(bbocr_ctx* ctx, int which) {
     return guarded(ctx, [&] {
         if (which != 0 && which != 1) fail(BBOCR_ERR_ARG, "which: 0 = detector, 1 = recogniser");
+        if (which == 0 ? ctx->craft_loaded : ctx->crnn_loaded)
+            fail(BBOCR_ERR_STATE, "this network is already laid out in this context -- create a new context");
         TensorMap tm;                        // every tensor present, all zeros: lays the packed plans out, bbocr_weights_import fills them
         if (which == 0) load_craft(ctx, tm);
         else load_crnn(ctx, tm);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -104,3 +105,33 @@ static inline constexpr int diag_knob(const char*, int dflt) { return dflt; }
             throw std::string(#expr) + ": " + hipGetErrorString(_e);                       \
         }                                                                                  \
     } while (0)
+
+// ---- per-DEVICE launch state.  hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device) and the CU count is the
+// device's: a process may hold contexts on several cards (bbocr_config::device), so neither may live in a process-wide flag.
+static constexpr int kMaxDev = 32;
+struct LdsOptIn {
+    std::atomic<size_t> hw[kMaxDev];   // per device: the largest dynamic LDS size this function has been opted in for (static storage: zero)
+};
+static inline hipError_t lds_opt_in(LdsOptIn& st, const void* fn, size_t smem) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    if (d < 0 || d >= kMaxDev) return hipErrorInvalidDevice;
+    size_t cur = st.hw[d].load(std::memory_order_acquire);
+    if (smem <= cur) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);     // idempotent: a racing thread sets the same value
+    if (e != hipSuccess) return e;
+    while (cur < smem && !st.hw[d].compare_exchange_weak(cur, smem, std::memory_order_release)) {}
+    return hipSuccess;
+}
+static inline int device_cus() {
+    static std::atomic<int> n[kMaxDev];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) return 256;
+    int v = n[d].load(std::memory_order_acquire);
+    if (v) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    n[d].store(v, std::memory_order_release);
+    return v;
+}

@@ -1135,25 +1135,15 @@ template <int EL>
 static hipError_t launch_resw(const ConvArgs& a, hipStream_t s) {
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     static const int db_knob = diag_knob("BBOCR_RESW_DB", 1);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    auto go = [&](auto kern, size_t smem, int per_cu, bool& attr) -> hipError_t {
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+    const int ncu = device_cus();
+    auto go = [&](auto kern, size_t smem, int per_cu, LdsOptIn& attr) -> hipError_t {
+        if (hipError_t e = lds_opt_in(attr, (const void*)kern, smem); e != hipSuccess) return e;
         const int grid = ntiles < ncu * per_cu ? ntiles : ncu * per_cu;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
         return hipGetLastError();
     };
     constexpr size_t P = 324 * 64, W1 = 9 * 2048, W2 = 18 * 2048;
-    static bool at[5] = {false, false, false, false, false};
+    static LdsOptIn at[5];
     if (a.cout_store == 64) return go(conv3x3_resw_kernel<EL, 1, true, 4, true>, 9 * 4096 + 2 * P, 2, at[4]);       // 78.3 KB: two workgroups per CU
     if (a.nchunks == 1) {
         if (db_knob) return go(conv3x3_resw_kernel<EL, 1, true>, W1 + 2 * P, 2, at[0]);          // 59.9 KB: two workgroups per CU
@@ -1333,20 +1323,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
 template <int EL>
 static hipError_t launch_up4_el(const ConvArgs& a, hipStream_t s) {
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = device_cus();
     const size_t smem = 18 * 2048 + 2 * 324 * 64 + 256;  // 78.6 KB: two workgroups per CU
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_up4_kernel<EL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    static LdsOptIn attr;
+    if (hipError_t e = lds_opt_in(attr, (const void*)conv3x3_up4_kernel<EL>, smem); e != hipSuccess) return e;
     const int grid = ntiles < 2 * ncu ? ntiles : 2 * ncu;
     hipLaunchKernelGGL(conv3x3_up4_kernel<EL>, dim3(grid), dim3(256), smem, s, a);
     return hipGetLastError();
@@ -1464,12 +1444,8 @@ static hipError_t launch_dma1x1_k(const ConvArgs& a, long long grid, hipStream_t
     constexpr int RING = 3, NPX = WM * MF * 16;
     auto k = conv1x1_dma_kernel<EL, WM, WN, MF, RING, ADDUP>;
     const size_t smem = (size_t)RING * ((size_t)WN * 64 * 64 + (size_t)NPX * 64);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    static LdsOptIn attr;
+    if (hipError_t e = lds_opt_in(attr, (const void*)k, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((int)grid), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError();
 }
@@ -1519,12 +1495,8 @@ void pack_conv_weights(const ConvPlan& p, const float* w, uint16_t* out) {
 template <int EL, int WM, int WN, int MF, int PITER>
 static hipError_t launch_one(const ConvArgs& a, size_t smem, int grid, hipStream_t s) {
     auto k = conv_mfma_kernel<EL, WM, WN, MF, PITER>;
-    static size_t cur = 0;   // per-instantiation high-water mark of the opt-in dynamic LDS size
-    if (smem > cur) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        cur = smem;
-    }
+    static LdsOptIn attr;    // per instantiation and device: high-water mark of the opt-in dynamic LDS size
+    if (hipError_t e = lds_opt_in(attr, (const void*)k, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), smem, s, a);
     return hipGetLastError();
 }
@@ -1560,12 +1532,8 @@ static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
     // FOUR share a CU -- these launches are bound by per-tile latency, not by MFMA or HBM
     static const bool one_buf = (diag_knob("BBOCR_CONV_1BUF", 1) != 0);   // A/B knob
     const size_t smem = (one_buf && a.nchunks == 1 && !FUSE1) ? smem_max - (size_t)NPS * 64 : smem_max;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    static LdsOptIn attr;
+    if (hipError_t e = lds_opt_in(attr, (const void*)k, smem_max); e != hipSuccess) return e;
     if (const char* dir = conv_stamps_dir()) {
         static int seq = 0;
         unsigned long long* dev = nullptr;

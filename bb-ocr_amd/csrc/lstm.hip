@@ -401,26 +401,18 @@ hipError_t launch_lstm(const void* xproj, const uint16_t* whh_pk, uint16_t* out,
     if (ntiles <= 0) return hipSuccess;
     if (mode == REC_SPLIT) {
         const size_t smemx = (size_t)2 * 2 * LSTMX_NG * 32 * 16 * 16;
-        static bool attrx = false;
-        if (!attrx) {
-            hipError_t e = hipFuncSetAttribute((const void*)lstm_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemx);
-            if (e != hipSuccess) return e;
-            attrx = true;
-        }
+        static LdsOptIn attrx;
+        if (hipError_t e = lds_opt_in(attrx, (const void*)lstm_exact_kernel, smemx); e != hipSuccess) return e;
         hipLaunchKernelGGL(lstm_exact_kernel, dim3(ntiles, 2), dim3(512), smemx, s, (const float*)xproj, whh_pk, out, (const int4*)tiles_dev, acc_scale);
         return hipGetLastError();
     }
     const size_t smem8 = 2 * 32 * 16 * 16 + (size_t)8 * LSTM8_NL * 1024;
     static const int pf_dist = diag_knob("BBOCR_LSTM_PF", 2);   // x prefetch distance in steps (0 = off)
-    auto go = [&](auto kern, bool& attr) -> hipError_t {
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+    auto go = [&](auto kern, LdsOptIn& attr) -> hipError_t {
+        if (hipError_t e = lds_opt_in(attr, (const void*)kern, smem8); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(ntiles, 2), dim3(512), smem8, s, (const uint16_t*)xproj, whh_pk, out, (const int4*)tiles_dev, pf_dist);
         return hipGetLastError();
     };
-    static bool attr_bf = false, attr_f16 = false;
+    static LdsOptIn attr_bf, attr_f16;
     return mode == REC_F16 ? go(lstm8_kernel<1>, attr_f16) : go(lstm8_kernel<0>, attr_bf);
 }

@@ -120,9 +120,15 @@ void free_weights(bbocr_ctx* c) {
 // bbocr_alloc_weights) import it: no fp32 state-dict, no host hop and no re-packing on the receivers (~49 MB in
 // bf16 instead of 98 MB of fp32).
 namespace {
-struct BlobHeader { unsigned long long magic; int precision, nblocks; unsigned long long bytes; int craft, crnn; int pad[8]; };
+struct BlobHeader { unsigned long long magic; int precision, nblocks; unsigned long long bytes; int craft, crnn; unsigned long long layout_hash; int pad[6]; };
 static_assert(sizeof(BlobHeader) == 64, "blob header");
 constexpr unsigned long long BLOB_MAGIC = 0x62626f6372776231ULL;   // "bbocrwb1"
+unsigned long long layout_hash(const bbocr_ctx* c) {     // FNV-1a over the per-block sizes: equal totals with different blocks do not pass
+    unsigned long long h = 1469598103934665603ULL;
+    for (size_t b : c->owned_bytes)
+        for (int i = 0; i < 8; ++i) { h ^= (unsigned long long)((b >> (8 * i)) & 0xff); h *= 1099511628211ULL; }
+    return h;
+}
 std::vector<float*> blob_scalars(bbocr_ctx* c) {       // host scalars that depend on the weight VALUES (power-of-two scales of split plans)
     std::vector<float*> v;
     for (ConvPlan* p : {&c->r1, &c->r2, &c->r3, &c->r4, &c->r5, &c->r6, &c->xproj[0], &c->xproj[1], &c->lin[0], &c->lin[1], &c->pred}) v.push_back(&p->acc_scale);
@@ -143,7 +149,7 @@ void weights_export(bbocr_ctx* c, void* dev_dst, size_t bytes) {
     if (bytes != weights_blob_bytes(c)) fail(BBOCR_ERR_ARG, "weight blob: wrong size");
     BlobHeader h{};
     h.magic = BLOB_MAGIC; h.precision = c->cfg.precision; h.nblocks = (int)c->owned.size(); h.bytes = bytes;
-    h.craft = c->craft_loaded; h.crnn = c->crnn_loaded;
+    h.craft = c->craft_loaded; h.crnn = c->crnn_loaded; h.layout_hash = layout_hash(c);
     char* d = (char*)dev_dst;
     HIPCHK(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     size_t off = sizeof(h);
@@ -164,7 +170,7 @@ void weights_import(bbocr_ctx* c, const void* dev_src, size_t bytes) {
     BlobHeader h{};
     HIPCHK(hipMemcpy(&h, s, sizeof(h), hipMemcpyDeviceToHost));
     if (h.magic != BLOB_MAGIC || h.precision != c->cfg.precision || h.nblocks != (int)c->owned.size() || h.bytes != bytes ||
-        h.craft != (int)c->craft_loaded || h.crnn != (int)c->crnn_loaded)
+        h.craft != (int)c->craft_loaded || h.crnn != (int)c->crnn_loaded || h.layout_hash != layout_hash(c))
         fail(BBOCR_ERR_WEIGHTS, "weight blob does not match this context (precision, networks or layout differ)");
     size_t off = sizeof(h);
     for (size_t i = 0; i < c->owned.size(); ++i) {

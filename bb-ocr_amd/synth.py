@@ -16,12 +16,13 @@ _WORDS = ("the quick brown fox jumps over lazy dog beyond frontier romance of ea
 
 
 def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_size: int = 24, word_gap: int = 16, line_pitch: int = 40,
-         margin: int = 48, colour: bool = False):
+         margin: int = 48, colour: bool = False, vocab=None):
     """-> (rgb uint8 [H,W,3], word boxes [(x0,y0,x1,y1,text)]).
 
     ``colour=True`` tints paper and ink (a per-page offset on the red and blue channels plus per-pixel chroma noise; the green
     channel -- the one the designed detector reads -- keeps the grey page's values), so that R != G != B everywhere and the
-    gray plane (cv2 BGR2GRAY on the device) is a genuine three-channel mix."""
+    gray plane (cv2 BGR2GRAY on the device) is a genuine three-channel mix.
+    ``vocab`` replaces the built-in word list (tests/golden/train_crnn.py mixes in random letter strings)."""
     from PIL import Image, ImageDraw, ImageFont
 
     rng = np.random.default_rng(seed)
@@ -33,6 +34,7 @@ def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_
     draw = ImageDraw.Draw(mask)
     draw.fontmode = "1"
     words = []
+    vocab = _WORDS if vocab is None else vocab
     y = margin
     for _ in range(lines):
         if y + line_pitch > height - margin // 2:
@@ -40,7 +42,7 @@ def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_
         x = margin + int(rng.integers(0, 24))
         limit = width - margin - int(rng.integers(0, width // 3))
         while True:
-            w = _WORDS[int(rng.integers(0, len(_WORDS)))]
+            w = vocab[int(rng.integers(0, len(vocab)))]
             if rng.random() < 0.15:
                 w = w.capitalize()
             bb = draw.textbbox((x, y), w, font=font)

@@ -80,8 +80,11 @@ def _signal(sd, conv, bn, out_ch, taps, bias):
 def designed_craft_state(seed: int = 0) -> dict:
     """Random CRAFT + an ink-detector sub-network (see module docstring).
 
-    region = 0.25 * B, affinity = 0.08 * L where, at half resolution, I = 2x2 max-pooled binary ink,
+    region = 0.25 * B, affinity = 0.073 * L where, at half resolution, I = 2x2 max-pooled binary ink,
     B = 3x3 box sum of I and L = B filtered twice with [1,1,1] horizontally.  Dark-on-light pages only.
+    B and L are integers on binary ink, so both maps live on a lattice: region 0.25 k (thresholds 0.4 / 0.7 fall between 0.25 | 0.5 and
+    0.5 | 0.75), affinity 0.073 k (0.4 falls between 0.365 | 0.438).  Round 2 used 0.08, whose fifth multiple IS the link threshold:
+    ~100 pixels per page sat exactly on `link > 0.4`, where the fp32 oracle itself decides by its last bit (tools/flip_report.py).
     Ink is a BAND of grey levels (full response for green <= 16 .. 96, none at pure black): the zero canvas that
     ``resize_aspect_ratio`` pads a page with (a 13-pixel stripe beside a 2480x3504 scan) is not text, as for a trained CRAFT.
     """
@@ -111,7 +114,7 @@ def designed_craft_state(seed: int = 0) -> dict:
     _signal(sd, "conv_cls.6", None, 0, {0: [[1.0]]}, 0.0)
     _signal(sd, "conv_cls.6", None, 1, {1: [[1.0]]}, 0.0)
     _signal(sd, "conv_cls.8", None, 0, {0: [[0.25]]}, 0.0)
-    _signal(sd, "conv_cls.8", None, 1, {1: [[0.08]]}, 0.0)
+    _signal(sd, "conv_cls.8", None, 1, {1: [[0.073]]}, 0.0)
     return sd
 
 
@@ -163,6 +166,12 @@ def load_checkpoint(path: str) -> dict:
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def load_npz_state(path: str) -> dict:
+    """A state-dict stored as ``.npz`` (upstream key names, any float dtype) -> {name: numpy fp32}."""
+    with np.load(path) as z:
+        return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
 
 
 def load_checkpoint_dir(directory: str):

@@ -9,13 +9,22 @@ synthetic 1280x960 pages per GPU, pages already resident in HBM.  Workload = BAS
 ("Full CRAFT+CRNN detect+recognize, batch=64 @1280x960, 1 MI355X"); with N GPUs every rank processes its own
 64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL) -- at N = 8
 that is BASELINE.json configs[3] (512 pages sharded across 8 MI355X).  `--config a4` runs configs[4]'s per-GPU share
-instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision
-(bf16 default; fp16; exact = split-fp16 recogniser whose text equals the fp32 CPU path's).
+instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision.
+
+Weights: the designed detector (bb_ocr_amd.weights.designed_craft_state) and the recogniser checkpoint trained on these
+synthetic pages (tests/golden/crnn_synth_fp16.npz, tests/golden/train_crnn.py) -- a recogniser that reads the pages has the
+top-2 logit margins of a trained model, so "same text as the fp32 CPU path" is measurable (`parity_in_run`).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (conv_mfma, detector launches): algorithmic FLOPs / sum of launch durations
-                  measured with HIP events on the library's stream inside the timed region; peak = 2.5 PFLOP/s dense bf16.
-  cpu_baseline -- the CPU oracle (restatement of the easyocr algorithm, kind "port") timed on this host, N=1 only.
+  roofline      -- the dominant kernel (conv_mfma, detector launches): algorithmic FLOPs / sum of launch durations
+                   measured with HIP events on the library's stream inside the timed region; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline  -- the CPU oracle (restatement of the easyocr algorithm, kind "port") timed on this host, N=1 only.
+  parity_in_run -- the SAME pages the CPU oracle just read, compared with what the timed GPU step returned for them:
+                   boxes identical n/m, texts identical n/m.
+  legs          -- N=1 only, after the timed region: a few steps each of the other driver-visible modes
+                   (`--precision exact`, `--config a4`), own readers, own roofline fractions.
+  N > 1         -- ranks_seen, devices (per-rank PCI bus id / uuid, all-gathered; must be distinct under nccl),
+                   weights_broadcast_ok (a failed broadcast is fatal unless --allow-local-weights).
 """
 from __future__ import annotations
 
@@ -35,6 +44,138 @@ CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, 
     "a4": (2480, 3504, 16, 110, 31, "fp16", "A4@300dpi 2480x3504 dense-text scans, fp16 MFMA conv path, 16 pages per GPU "
                                            "(BASELINE.json configs[4]: batch=128 on 8 GPUs)"),
 }
+TRAINED_CRNN = os.path.join(ROOT, "tests", "golden", "crnn_synth_fp16.npz")
+METRIC = {"p1": "book-page images/sec end-to-end (detect+recognize) @1280x960",
+          "a4": "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)"}
+DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)"}
+
+
+def log(msg, rank=0):
+    if rank == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def load_states(rec_weights):
+    """(craft_state, crnn_state, label).  The trained recogniser is a test-infrastructure checkpoint; it enters like any state-dict."""
+    from bb_ocr_amd import weights
+
+    cs = weights.designed_craft_state(0)
+    if rec_weights == "trained":
+        if not os.path.exists(TRAINED_CRNN):
+            raise SystemExit(f"{TRAINED_CRNN} is missing (tests/golden/train_crnn.py writes it); --rec-weights random runs without it")
+        return cs, weights.load_npz_state(TRAINED_CRNN), "seeded designed-detector weights + the recogniser trained on these synthetic pages (tests/golden/crnn_synth_fp16.npz)"
+    return cs, weights.synthetic_crnn_state(0), "seeded designed-detector + random-recogniser weights"
+
+
+def page_kwargs(config, width, height, lines):
+    kw = dict(width=width, height=height, lines=lines, line_pitch=CONFIGS[config][4], margin=24)
+    if config == "a4":
+        kw.update(font_size=20, word_gap=14, margin=60)
+    return kw
+
+
+def render_pages(config, width, height, lines, first, count, unique):
+    """Seeded pages: every other one on tinted stock / coloured ink so that the gray plane is a real 3-channel mix."""
+    from bb_ocr_amd import synth
+
+    kw = page_kwargs(config, width, height, lines)
+    return [synth.page(1234 + (first + i), colour=bool((first + i) & 1), **kw)[0] for i in range(min(unique, count))]
+
+
+def timed_steps(reader, rgb, steps, warmup, dist=None, backend="nccl", rank=0, tag=""):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  -> (seconds, stage sums, last result)."""
+    import torch
+
+    import bb_ocr_amd
+
+    for _ in range(warmup):
+        out = reader.readtext_device(rgb, None)
+        log(f"{tag}warm-up step done: {reader.stage_times()}", rank)
+    reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
+    if os.environ.get("BBOCR_BENCH_NOFREEZE") != "1":
+        bb_ocr_amd.freeze_gc()   # host-process hygiene of a long-running OCR worker (see freeze_gc.__doc__)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage, out = {}, None
+    for _ in range(steps):
+        out = reader.readtext_device(rgb, None)
+        for k, v in reader.stage_times().items():
+            stage[k] = stage.get(k, 0.0) + v
+        log(f"{tag}timed step done", rank)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, stage, out
+
+
+def roofline(reader, config, batch, steps):
+    conv_ms, conv_flops, conv_launches = reader.conv_profile(0)
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    return {
+        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel + conv3x3_up4_kernel + conv3x3_resw_kernel (every conv launch of the detector passes -- 25 per pass "
+                  "at 1280x960: conv1_1+conv1_2 fused .. upconv3.3x3 + upconv4.1x1(y) .. upconv4 fused .. conv_cls.4+tail)",
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+        # HBM bytes are not measurable from inside the process; the PMC passes of the same detector are committed under profiles/
+        # (r03_pmc_hbm.json, tools/pmc_traffic.py) -- a constant copied from a file would not be a measurement of THIS run
+        "traffic": None,
+        "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
+        "algorithmic_gflop_per_page": conv_flops / 1e9 / max(batch * steps, 1),
+        "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE[config],
+    }
+
+
+def device_identity(local_rank):
+    """What distinguishes this rank's card: PCI bus id (hipDeviceGetPCIBusId) and, when torch exposes it, the device uuid."""
+    import ctypes
+
+    import torch
+
+    ident = {"local_rank": local_rank, "name": torch.cuda.get_device_name(local_rank), "pci_bus_id": None, "uuid": None}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+    except OSError:
+        pass
+    try:
+        ident["uuid"] = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:
+        pass
+    return ident
+
+
+def run_leg(name, config, precision, steps, states, args):
+    """One of the other driver-visible modes on this card, after the main timed region: own reader, own pages."""
+    import numpy as np
+    import torch
+
+    import bb_ocr_amd
+
+    cw, ch, cb, cl, _, _, workload = CONFIGS[config]
+    t_leg = time.perf_counter()
+    reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision=precision)
+    try:
+        uniq = render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else args.unique)
+        rgb = torch.from_numpy(np.stack([uniq[i % len(uniq)] for i in range(cb)])).cuda()
+        dt, stage, out = timed_steps(reader, rgb, steps, 1, tag=f"[leg {name}] ")
+        rf = roofline(reader, config, cb, steps)
+        return {"metric": METRIC[config], "value": cb * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": 1,
+                "dtype": DTYPE[precision], "config": {"workload": workload, "precision": precision, "batch_per_gpu": cb,
+                                                      "boxes_per_step": sum(len(p) for p in out), "chars_per_step": sum(len(t) for p in out for _, t, _ in p)},
+                "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
+                "stage_ms_per_step": {k: v / steps for k, v in stage.items()}, "leg_seconds": time.perf_counter() - t_leg}
+    finally:
+        reader.close()
+        del reader
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -49,11 +190,16 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact"), default=None, help="bbocr_config::precision (default: the config's)")
-    ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline after one warm-up page (0 = skip)")
+    ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
+    ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
+    ap.add_argument("--legs", default="exact,a4", help="N=1: extra modes run after the timed region (comma list of exact, a4; '' = none)")
+    ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 renders every rank's pages and scatters them (dist.scatter_pages: grouped "
                                                            "RCCL sends over xGMI) instead of every rank rendering its own shard; outside the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--allow-local-weights", action="store_true", help="N > 1: if the packed weight broadcast fails, build the seeded weights on every rank "
+                                                                       "and continue (reported as weights_broadcast_ok false) instead of exiting non-zero")
     args = ap.parse_args()
     cw, ch, cb, cl, cpitch, cprec, workload = CONFIGS[args.config]
     args.width, args.height = args.width or cw, args.height or ch
@@ -82,37 +228,54 @@ def main():
 
     import bb_ocr_amd
     from bb_ocr_amd import dist as bdist
-    from bb_ocr_amd import synth, weights
 
     # ---- weights: built and packed on rank 0, broadcast ONCE as the packed device blob (RCCL, device to device over xGMI) -- the
     # process-per-GPU form of DataParallel's per-forward replicate; the other ranks never see an fp32 state-dict
     cs = rs = None
-    if rank == 0:
-        cs, rs = weights.designed_craft_state(0), weights.synthetic_crnn_state(0)
+    weights_label = ""
+    if rank == 0 or world == 1:
+        cs, rs, weights_label = load_states(args.rec_weights)
     mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
-    weights_path = "local (single process)"
+    weights_path, broadcast_ok, devices = "local (single process)", None, None
     if world > 1:
+        # who is here: every rank's card, all-gathered (a SCALE run can be checked for N distinct devices from the JSON alone)
+        devices = [None] * world
+        dist.all_gather_object(devices, dict(device_identity(local_rank), rank=rank))
+        if args.backend == "nccl":
+            ids = [d["pci_bus_id"] or d["uuid"] or f"local{d['local_rank']}" for d in devices]
+            if len(set(ids)) != world:
+                raise SystemExit(f"ranks share a device under nccl: {ids}")
+        reader, err = None, None
+        t_b = time.perf_counter()
         try:
-            t_b = time.perf_counter()
             reader = bdist.broadcast_packed(lambda: mk((cs, rs)), lambda: mk("empty"), src=0, via_host=(args.backend != "nccl"))
+        except Exception as e:
+            err = e
+            print(f"[bench rank {rank}] packed weight broadcast failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        # agree on the outcome before anyone goes on (a rank-local failure must not leave the others inside a later collective)
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        broadcast_ok = bool(int(flag.item()))
+        if broadcast_ok:
             weights_path = (f"packed device blob ({reader.weights_blob_size() / 1e6:.1f} MB) broadcast from rank 0 over "
                             f"{'RCCL, device to device' if args.backend == 'nccl' else args.backend + ' (host hop: rehearsal only)'} "
                             f"in {(time.perf_counter() - t_b) * 1e3:.0f} ms incl. packing")
-        except Exception as e:      # a measurement must not die on the one-off setup collective: the weights are seeded, every rank can build them
-            print(f"[bench rank {rank}] packed weight broadcast failed ({type(e).__name__}: {e}); building the seeded weights locally", file=sys.stderr, flush=True)
-            reader = mk((weights.designed_craft_state(0), weights.synthetic_crnn_state(0)))
-            weights_path = f"local on every rank (broadcast failed: {type(e).__name__})"
+        else:
+            if reader is not None:
+                reader.close()           # no second set of weights / second arena on the card
+            if not args.allow_local_weights:
+                dist.destroy_process_group()
+                raise SystemExit("the packed weight broadcast failed on at least one rank; --allow-local-weights lets every rank build the seeded weights instead")
+            cs, rs, weights_label = load_states(args.rec_weights)
+            reader = mk((cs, rs))
+            weights_path = "local on every rank (the packed broadcast FAILED; --allow-local-weights)"
     else:
         reader = mk((cs, rs))
 
     # ---- this rank's shard of the global batch (contiguous block), rendered on the host, then resident in HBM
     B = args.batch
     g0, g1 = bdist.shard_range(B * world, rank, world)
-    # seeded pages: every other one on tinted stock / coloured ink so that the gray plane is a real 3-channel mix
-    page_kw = dict(width=args.width, height=args.height, lines=args.lines, line_pitch=cpitch, margin=24)
-    if args.config == "a4":
-        page_kw.update(font_size=20, word_gap=14, margin=60)
-    render = lambda a, n: [synth.page(1234 + (a + i), colour=bool((a + i) & 1), **page_kw)[0] for i in range(min(args.unique, n))]
+    render = lambda a, n: render_pages(args.config, args.width, args.height, args.lines, a, n, args.unique)
     pages_path = "every rank renders its own shard (no scatter)"
     if args.scatter and world > 1:
         # BASELINE.json configs[3] names an image scatter: the loader rank holds all pages and sends every rank its block
@@ -138,39 +301,9 @@ def main():
         rgb = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-    def step():
-        return reader.readtext_device(rgb, None)
-
-    log(f"pages resident: {tuple(rgb.shape)}; warm-up x{args.warmup}")
-    for _ in range(args.warmup):
-        out = step()
-        log(f"warm-up step done: {reader.stage_times()}")
-    reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
-    if os.environ.get("BBOCR_BENCH_NOFREEZE") != "1":
-        bb_ocr_amd.freeze_gc()   # host-process hygiene of a long-running OCR worker (see freeze_gc.__doc__): full GC passes stop re-walking torch
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stage = {}
-    for _ in range(args.steps):
-        out = step()
-        for k, v in reader.stage_times().items():
-            stage[k] = stage.get(k, 0.0) + v
-        log("timed step done")
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    conv_ms, conv_flops, conv_launches = reader.conv_profile(0)
+    log(f"pages resident: {tuple(rgb.shape)}; warm-up x{args.warmup}", rank)
+    dt, stage, out = timed_steps(reader, rgb, args.steps, args.warmup, dist, args.backend, rank)
+    rf = roofline(reader, args.config, B, args.steps)
     n_boxes = sum(len(p) for p in out)
     n_chars = sum(len(t) for p in out for _, t, _ in p)
 
@@ -181,8 +314,7 @@ def main():
 
     pages = B * world * args.steps
     result = {
-        "metric": "book-page images/sec end-to-end (detect+recognize) @1280x960" if args.config == "p1" else
-                  "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)",
+        "metric": METRIC[args.config],
         "value": pages / dt,
         "unit": "images/s",
         "n_gpus": world,
@@ -192,8 +324,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)"}[args.precision],
-        "data": f"synthetic ({len(uniq)} distinct seeded pages per GPU tiled to the batch; seeded designed-detector + random-recogniser weights)",
+        "dtype": DTYPE[args.precision],
+        "data": f"synthetic ({len(uniq)} distinct seeded pages per GPU tiled to the batch; {weights_label})",
         "config": {
             "workload": workload if not (args.config == "p1" and world == 8) else
                         "batch=512 @1280x960 sharded across 8 MI355X, 64 pages per GPU (BASELINE.json configs[3]; RCCL weight broadcast, "
@@ -204,35 +336,58 @@ def main():
             "weights": weights_path, "pages": pages_path,
         },
         "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stage.items()},
+        "roofline": rf,
     }
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of the
-    # same detector, reads = 2 x FETCH_SIZE KiB on gfx950), scaled by the pages the average launch of THIS run processed
-    traffic, traffic_src = None, None
-    pmc_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    pmc = next((os.path.join(pmc_dir, n) for n in ("r02_pmc_hbm.json", "r01_pmc_hbm.json") if os.path.exists(os.path.join(pmc_dir, n))), None)
-    if pmc and conv_launches > 0 and args.config == "p1" and args.precision == "bf16":
-        with open(pmc) as f:
-            t = json.load(f)
-        traffic = (t["read_MB_per_page"] + t["write_MB_per_page"]) * 1e6 * B * args.steps / conv_launches
-        traffic_src = (f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same detector, committed as profiles/{os.path.basename(pmc)} "
-                       f"({t['read_MB_per_page']:.0f} MB read + {t['write_MB_per_page']:.0f} MB written per page), scaled to bytes per average launch")
-    result["roofline"] = {
-        "kernel": "conv3x3_dma_kernel + conv1x1_dma_kernel + conv3x3_up4_kernel + conv3x3_resw_kernel (every conv launch of the detector passes -- 25 per pass at this page size: conv1_1+conv1_2 fused .. upconv3.3x3 + upconv4.1x1(y) .. upconv4 fused .. conv_cls.4+tail)",
-        "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-        "traffic": traffic, "traffic_source": traffic_src,
-        "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
-        "algorithmic_gflop_per_page": conv_flops / 1e9 / max(B * args.steps, 1),
-        "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE[args.config],
-        # (the recogniser's ~500 launches per step overlap on side streams and are not event-timed in the measured run:
-        #  Reader.set_profiling(2) + conv_profile(1) gives their busy time)
-    }
-    log(f"GPU legs done: {pages / dt:.1f} images/s; CPU baseline next")
-    if world == 1 and args.cpu_pages > 0:
-        result["cpu_baseline"] = cpu_baseline(cs, rs, uniq, args.cpu_pages, (args.width, args.height))
+    if world > 1:
+        result["ranks_seen"] = len([d for d in devices if d is not None])
+        result["devices"] = devices
+        result["weights_broadcast_ok"] = broadcast_ok
+    log(f"timed region done: {pages / dt:.1f} images/s", rank)
+    if world == 1:
+        reader.close()
+        del reader
+        torch.cuda.empty_cache()
+        legs = {}
+        for name in [s for s in args.legs.split(",") if s]:
+            if name == "exact" and not (args.config == "p1" and args.precision == "exact"):
+                legs["exact"] = run_leg("exact", "p1", "exact", args.leg_steps, (cs, rs), args)
+            elif name == "a4" and args.config != "a4":
+                legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs), args)
+            if legs:
+                log(f"leg {name}: {list(legs.values())[-1]['value']:.1f} images/s")
+        if legs:
+            result["legs"] = legs
+        if args.cpu_pages > 0:
+            log("CPU baseline next")
+            result["cpu_baseline"], ref_pages = cpu_baseline(cs, rs, uniq, args.cpu_pages, (args.width, args.height))
+            result["parity_in_run"] = parity(ref_pages, out, args.precision)
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def parity(ref_pages, gpu_pages, mode):
+    """The pages the CPU oracle read (indices 0..n-1 of this rank's batch) against what the last TIMED GPU step returned for them."""
+    import numpy as np
+
+    boxes = same_boxes = same_text = pages_same = 0
+    worst = None
+    for want, got in zip(ref_pages, gpu_pages):
+        boxes += len(want)
+        ok_page = len(want) == len(got)
+        for w, g in zip(want, got):
+            b = np.array_equal(np.asarray(w[0], dtype=np.float64), np.asarray(g[0], dtype=np.float64))
+            t = w[1] == g[1]
+            same_boxes += b
+            same_text += t
+            ok_page = ok_page and b and t
+            if not t and worst is None:
+                worst = {"oracle": w[1], "gpu": g[1]}
+        pages_same += ok_page
+    return {"pages": len(ref_pages), "mode": mode, "boxes": boxes, "boxes_identical": f"{same_boxes}/{boxes}", "texts_identical": f"{same_text}/{boxes}",
+            "pages_identical": f"{pages_same}/{len(ref_pages)}", "all_identical": bool(same_boxes == boxes and same_text == boxes),
+            "first_text_difference": worst,
+            "what": "oracle.pipeline.OracleReader.readtext (fp32 CPU) vs the last timed GPU step's result for the same pages: box coordinates equal as numbers, decoded strings equal"}
 
 
 def cpu_model():
@@ -248,7 +403,8 @@ def cpu_model():
 
 def cpu_baseline(cs, rs, pages, n_pages, wh):
     """The oracle (CPU restatement of the same algorithm, batch 1 per page and per box like the reference's readtext call) on this host's
-    cores: one warm-up page, then n pages timed one by one; value = 1 / median seconds per page."""
+    cores: one warm-up page, then n pages timed one by one; value = 1 / median seconds per page.
+    -> (cpu_baseline object, the oracle's per-page results for parity_in_run)."""
     import statistics
 
     import torch
@@ -265,18 +421,19 @@ def cpu_baseline(cs, rs, pages, n_pages, wh):
     ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
     n = min(n_pages, len(pages))
     ref.readtext(pages[0])                                   # warm-up (thread pool, oneDNN primitive caches)
-    per_page, nb = [], 0
+    per_page, nb, results = [], 0, []
     t_all = time.perf_counter()
     for i in range(n):
         t0 = time.perf_counter()
-        nb += len(ref.readtext(pages[i]))
+        results.append(ref.readtext(pages[i]))
         per_page.append(time.perf_counter() - t0)
+        nb += len(results[-1])
     med = statistics.median(per_page)
     return {"value": 1.0 / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model(),
             "sample": f"CPU restatement (EasyOCR-equivalent algorithm, synthetic weights): {n} of the same synthetic {wh[0]}x{wh[1]} pages through "
                       f"oracle.pipeline.OracleReader.readtext (torch fp32 CPU, batch 1 per page and per box, {nb} boxes) after 1 warm-up page; "
                       f"value = 1 / median seconds per page",
-            "median_s_per_page": med, "seconds": time.perf_counter() - t_all}
+            "median_s_per_page": med, "seconds": time.perf_counter() - t_all}, results
 
 
 if __name__ == "__main__":

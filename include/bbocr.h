@@ -48,10 +48,16 @@ typedef struct bbocr_config {
                          *   BBOCR_PREC_EXACT (2) detector as FP16; recogniser in split fp16: every activation and weight is a pair
                          *                        hi + lo of fp16 values (22 significand bits) and every product runs as the three MFMA
                          *                        terms hi*hi + lo*hi + hi*lo accumulated in fp32, LSTM state and gates in fp32 --
-                         *                        the mode whose decoded TEXT equals the fp32 CPU path's (3x the recogniser's MFMA work) */
+                         *                        the mode whose decoded TEXT equals the fp32 CPU path's (3x the recogniser's MFMA work);
+                         *   BBOCR_PREC_MIXED (3) detector as BF16, recogniser as FP16: the cheapest arithmetic that decoded all of 2,000+
+                         *                        boxes of the 1280x960 workload to the fp32 CPU path's strings with identical boxes
+                         *                        (profiles/r03_text_parity.json) -- bf16 keeps the detector's clock (fp16 operands
+                         *                        toggle more bits under the power limit), the recogniser's 8x finer rounding keeps
+                         *                        its arg-max.
+                         * Any other value: bbocr_create returns BBOCR_ERR_ARG. */
     int reserved[4];
 } bbocr_config;
-enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2 };
+enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2, BBOCR_PREC_MIXED = 3 };
 
 /* One tensor of an upstream state-dict (easyocr/craft.py::CRAFT or easyocr/model/vgg_model.py::Model key names,
  * optional "module." prefix), fp32, host memory, C-contiguous.  Replaces torch.load + load_state_dict in
@@ -187,13 +193,13 @@ int bbocr_host_ctc_beam(const float* probs, int n, int T, int C, int cs, int bea
 /* ---- single-operator entry points (used by the parity tests; same kernels the pipeline runs) ---- */
 /* conv2d on device tensors: in bf16 NHWC [N,H,W,Cin] (as uint16 bits), weights fp32 OIHW on the host (+bias or NULL),
  * out bf16 (out_f32 = 0) or fp32 NHWC [N,OH,OW,Cout_store]; Cin % 32 == 0; Cout_store = roundup16(Cout).  With
- * bbocr_config::precision >= BBOCR_PREC_FP16 "bf16" reads "fp16" throughout (the context's element type).
+ * bbocr_config::precision FP16 / EXACT "bf16" reads "fp16" throughout (the DETECTOR's element type of the context; MIXED: bf16).
  * pool_mode 1/2 fuses MaxPool2d(2,2) / MaxPool2d((2,1),(2,1)) (optionally after ReLU: pool_relu) into the epilogue and
  * writes bf16 [N,OH/2,OW/2 or OW,Cout_store] to dev_pool_out; dev_out may then be NULL (pooled output only). */
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                     int KH, int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
                     uint16_t* dev_pool_out);
-/* recogniser network only: crops [n,64,imgW] (device, 16-bit elements of the context's precision: bf16 / fp16 values already
+/* recogniser network only: crops [n,64,imgW] (device, 16-bit elements of the context's RECOGNISER type: bf16 (BF16) / fp16 (FP16, MIXED) values already
  * normalised to [-1, 1]; BBOCR_PREC_EXACT: CODES, 0 = padding zero, 1 + grey level otherwise, from which the first layer rebuilds the
  * fp32 input ((g/255 - 0.5)/0.5) exactly) -> logits fp32 [n,T,112] (device), T = imgW/4-1 */
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits);

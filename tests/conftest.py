@@ -77,6 +77,44 @@ def reader_exact(states):
     r.close()
 
 
+TRAINED_CRNN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crnn_synth_fp16.npz")
+
+
+@pytest.fixture(scope="session")
+def states_trained():
+    """Designed detector + the recogniser TRAINED on the synthetic pages (tests/golden/train_crnn.py -> crnn_synth_fp16.npz): it reads
+    the rendered words, so its top-2 logit margins are those of a trained model and text identity with the fp32 oracle is measurable."""
+    from bb_ocr_amd import weights
+
+    return weights.designed_craft_state(0), weights.load_npz_state(TRAINED_CRNN)
+
+
+@pytest.fixture(scope="session")
+def oracle_trained(states_trained):
+    import torch
+
+    from oracle import pipeline
+
+    cs, rs = states_trained
+    return pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
+
+
+@pytest.fixture(scope="session")
+def readers_trained(states_trained):
+    """{precision: Reader} on the trained recogniser, built on first use."""
+    import bb_ocr_amd
+
+    class Lazy(dict):
+        def __missing__(self, precision):
+            self[precision] = bb_ocr_amd.Reader(["en"], gpu=True, weights=states_trained, precision=precision)
+            return self[precision]
+
+    d = Lazy()
+    yield d
+    for r in d.values():
+        r.close()
+
+
 class LogitTap:
     """Wraps an OracleReader so that the logits of every recogniser call are kept: the top-2 margins tell where an arg-max is
     numerically decidable (a character may differ from the oracle only where the oracle's own margin is below the noise

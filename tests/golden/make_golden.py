@@ -10,6 +10,8 @@ Two kinds of data:
     stored outputs are ref_images/book*_preprocessed.png (legacy preprocess_for_book_cover, image_preprocessor.py:221-252):
     five (input, output) vectors that pin the oracle's pre-processing stages (tests/test_oracle_cpu.py::test_legacy_preprocess_fixtures).
     Copied, not generated: `cp` from /root/reference (see copy_reference_images below).
+  * photos/IMG_968{4,5}.JPG -- pipeline_demo/books/2a/*.JPG, the inputs of ocr_comparison_IMG_968{4,5}.json (copied as data).
+  * crnn_synth_fp16.npz -- NOT made here: tests/golden/train_crnn.py (recogniser trained on the synthetic pages, test infrastructure).
   * oracle_*.npz -- seeded input/output vectors of the CPU oracle (oracle/), so that (a) the oracle cannot drift
     silently and (b) the GPU tests can compare against fixed numbers.  PARITY UNPINNED against real EasyOCR: neither the
     package nor its weights exist offline.
@@ -46,6 +48,11 @@ def copy_reference_images():
         shutil.copyfile(f"{root}/books/dataset/book{n}.png", os.path.join(HERE, "legacy_preprocess", f"book{n}.png"))
         shutil.copyfile(f"{root}/img_to_json/ocr_testing/results/images/book{n}_preprocessed.png",
                         os.path.join(HERE, "ref_images", f"book{n}_preprocessed.png"))
+    # the two photographs behind ocr_comparison_IMG_968{4,5}.json (BASELINE.json configs[0] names a single book-cover JPEG):
+    # real ragged / slanted / huge / tiny components for the box stages, the off-grid 1014x971 canvas, libjpeg's Y plane
+    os.makedirs(os.path.join(HERE, "photos"), exist_ok=True)
+    for n in ("IMG_9684.JPG", "IMG_9685.JPG"):
+        shutil.copyfile(f"/root/reference/pipeline_demo/books/2a/{n}", os.path.join(HERE, "photos", n))
 
 
 def reference_pairs():
