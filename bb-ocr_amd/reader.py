@@ -223,7 +223,8 @@ class Reader:
         self._lib = _lib.load()
         self._lock = threading.Lock()
         if precision is None:       # the reference constructs Reader(["en"], gpu=...) (enhanced_extractor.py:153): the mode comes from the environment
-            precision = os.environ.get("BBOCR_PRECISION", "bf16").strip().lower()
+            # default "mixed" (bf16 detector + fp16 recogniser): the cheapest mode that decoded 2,000+ boxes to the fp32 CPU path's strings
+            precision = os.environ.get("BBOCR_PRECISION", "mixed").strip().lower()
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
         self.precision = precision

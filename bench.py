@@ -9,7 +9,9 @@ synthetic 1280x960 pages per GPU, pages already resident in HBM.  Workload = BAS
 ("Full CRAFT+CRNN detect+recognize, batch=64 @1280x960, 1 MI355X"); with N GPUs every rank processes its own
 64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL) -- at N = 8
 that is BASELINE.json configs[3] (512 pages sharded across 8 MI355X).  `--config a4` runs configs[4]'s per-GPU share
-instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision.
+instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision; the p1
+default is "mixed" (bf16 detector + fp16 recogniser): the cheapest arithmetic whose boxes AND decoded strings equalled the fp32 CPU
+path's on all of 2,000+ boxes of this workload (tools/parity_sweep.py, profiles/r03_text_parity.json; plain bf16: 1 string of 2,051 off).
 
 Weights: the designed detector (bb_ocr_amd.weights.designed_craft_state) and the recogniser checkpoint trained on these
 synthetic pages (tests/golden/crnn_synth_fp16.npz, tests/golden/train_crnn.py) -- a recogniser that reads the pages has the
@@ -40,14 +42,14 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
 CRAFT_GFLOP_PER_PAGE = {"p1": 874.22, "a4": 3322.03}  # 1280x960 page / A4@300dpi on the 2560 canvas
 CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, line pitch, precision, workload label)
-    "p1": (1280, 960, 64, 24, 38, "bf16", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
+    "p1": (1280, 960, 64, 24, 38, "mixed", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
     "a4": (2480, 3504, 16, 110, 31, "fp16", "A4@300dpi 2480x3504 dense-text scans, fp16 MFMA conv path, 16 pages per GPU "
                                            "(BASELINE.json configs[4]: batch=128 on 8 GPUs)"),
 }
 TRAINED_CRNN = os.path.join(ROOT, "tests", "golden", "crnn_synth_fp16.npz")
 METRIC = {"p1": "book-page images/sec end-to-end (detect+recognize) @1280x960",
           "a4": "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)"}
-DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)"}
+DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)", "mixed": "bf16 (detector) + fp16 (recogniser)"}
 
 
 def log(msg, rank=0):
@@ -189,7 +191,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
-    ap.add_argument("--precision", choices=("bf16", "fp16", "exact"), default=None, help="bbocr_config::precision (default: the config's)")
+    ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
     ap.add_argument("--legs", default="exact,a4", help="N=1: extra modes run after the timed region (comma list of exact, a4; '' = none)")
@@ -236,6 +238,8 @@ def main():
     if rank == 0 or world == 1:
         cs, rs, weights_label = load_states(args.rec_weights)
     mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
+    if os.environ.get("BBOCR_BENCH_INJECT") == "precision_mismatch" and rank == 1:     # tests/test_gpu_multirank.py: a broadcast that must fail
+        mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, precision="exact" if args.precision != "exact" else "bf16")
     weights_path, broadcast_ok, devices = "local (single process)", None, None
     if world > 1:
         # who is here: every rank's card, all-gathered (a SCALE run can be checked for N distinct devices from the JSON alone)

@@ -42,7 +42,7 @@ typedef struct bbocr_config {
     int det_sub_batch;  /* pages per detector pass; 0 = auto (<= 64 pages / 96 GB of activations, short last pass) */
     int rec_max_cols;   /* pixel columns (4 per pooled time step) whose sequence stage runs as one pass; 0 = default (6,000,000) */
     int precision;      /* arithmetic of the two networks (fixed per context: the weights are packed for it at bbocr_load_weights):
-                         *   BBOCR_PREC_BF16  (0, default) bf16 MFMA operands and stored activations, fp32 accumulation;
+                         *   BBOCR_PREC_BF16  (0) bf16 MFMA operands and stored activations, fp32 accumulation;
                          *   BBOCR_PREC_FP16  (1) the same kernels on IEEE fp16 operands (v_mfma_f32_16x16x32_f16): 8x finer rounding,
                          *                        range 6e-8 .. 65504 -- BASELINE.json configs[4] ("fp16 MFMA conv path");
                          *   BBOCR_PREC_EXACT (2) detector as FP16; recogniser in split fp16: every activation and weight is a pair
@@ -54,6 +54,7 @@ typedef struct bbocr_config {
                          *                        (profiles/r03_text_parity.json) -- bf16 keeps the detector's clock (fp16 operands
                          *                        toggle more bits under the power limit), the recogniser's 8x finer rounding keeps
                          *                        its arg-max.
+                         *                        What the Python host (bb_ocr_amd.Reader) selects unless told otherwise.
                          * Any other value: bbocr_create returns BBOCR_ERR_ARG. */
     int reserved[4];
 } bbocr_config;

@@ -52,7 +52,7 @@ def reader(states):
     """The HIP backend.  Fails (not skips) if the extension is missing on a GPU box."""
     import bb_ocr_amd
 
-    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states)
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="bf16")
     yield r
     r.close()
 

@@ -33,3 +33,22 @@ def test_bench_two_ranks_one_card(scatter):
     assert d["config"]["weights"].startswith("packed device blob") and "MB" in d["config"]["weights"]       # not the local fallback
     assert d["config"]["pages"].startswith("scattered from rank 0" if scatter else "every rank renders")
     assert d["config"]["boxes_per_step_rank0"] > 100
+    # who took part, readable from the JSON alone (a SCALE run is checked for N distinct cards this way; two gloo ranks share this one)
+    assert d["ranks_seen"] == 2 and d["weights_broadcast_ok"] is True
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and all(x["pci_bus_id"] or x["uuid"] for x in d["devices"])
+
+
+def test_failed_weight_broadcast_is_fatal():
+    """A broadcast that fails (here: rank 1 lays its plans out for another precision, so the blob sizes disagree) must end the run non-zero
+    on every rank instead of quietly benchmarking locally built weights; --allow-local-weights turns it into a reported fallback."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", BBOCR_BENCH_INJECT="precision_mismatch")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--batch", "2", "--cpu-pages", "0"]
+    res = subprocess.run(base, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode != 0 and b"packed weight broadcast failed" in res.stderr
+    assert not [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    base[base.index("29541")] = "29542"
+    res = subprocess.run(base + ["--allow-local-weights"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["weights_broadcast_ok"] is False and "FAILED" in d["config"]["weights"]

@@ -15,10 +15,14 @@ from conftest import TRAINED_CRNN
 
 # boxes (of the full-page test below) whose decoded text may differ from the oracle's, per mode.  0 for the benchmarked default and for
 # `exact`; tools/parity_sweep.py measured the others on 2,000+ boxes (profiles/r03_text_parity.json).
-MAX_TEXT_MISMATCH = {"bf16": 0, "fp16": 0, "exact": 0}
+MAX_TEXT_MISMATCH = {"bf16": 1, "mixed": 0, "fp16": 0, "exact": 0}      # sweep: bf16 1 of 2,051; mixed / fp16 / exact 0 of 2,051
+# relative confidence error on boxes whose text agrees (max, median).  The confidence is custom_mean = prod(p_t over the non-blank steps)
+# ** (2 / sqrt(n)): ONE arg-max flip at a blank <-> character transition (p ~ 0.5 on both sides; the text does not change) adds or
+# removes a factor ~0.5 ** (2 / sqrt(n)) -- 18 % on a 50-step line, more on short words -- so only `exact` reproduces it closely
+CONF_BOUND = {"bf16": (1.0, 0.02), "mixed": (0.3, 0.004), "fp16": (0.3, 0.004), "exact": (1e-3, 1e-4)}
 # per time step: an arg-max may differ from the oracle's only where the ORACLE's own top-2 margin at THAT step (relative to the largest
 # |logit| of the crop) is below the mode's logit noise (compare per time step, not per box)
-STEP_MARGIN_BOUND = {"bf16": 6e-2, "fp16": 8e-3, "exact": 1e-4}
+STEP_MARGIN_BOUND = {"bf16": 6e-2, "mixed": 8e-3, "fp16": 8e-3, "exact": 1e-4}
 
 
 def _bench_pages(n, first=0):
@@ -49,16 +53,17 @@ def test_trained_checkpoint_reads_the_synthetic_page(oracle_trained):
 @pytest.mark.gpu
 def test_text_and_boxes_identical_on_full_size_pages(readers_trained, oracle_trained):
     """Four full-size 1280x960 bench pages (the oracle needs ~2.6 s each): every mode returns the oracle's boxes, exactly; decoded texts
-    differ on at most MAX_TEXT_MISMATCH[mode] boxes -- 0 in the benchmarked default mode and in `exact`; confidences agree."""
+    differ on at most MAX_TEXT_MISMATCH[mode] boxes -- 0 in the benchmarked default mode (`mixed`), in `fp16` and in `exact`; confidences
+    within CONF_BOUND."""
     pages = _bench_pages(4)
     want = [oracle_trained.readtext(p[0]) for p in pages]
     n_boxes = sum(len(w) for w in want)
     assert n_boxes >= 100
     rgb = torch.from_numpy(np.stack([p[0] for p in pages])).cuda()
     report = {}
-    for mode in ("bf16", "fp16", "exact"):
+    for mode in ("bf16", "mixed", "fp16", "exact"):
         got = readers_trained[mode].readtext_device(rgb)
-        bad_text, worst_conf = [], 0.0
+        bad_text, conf_err = [], []
         for pw, pg in zip(want, got):
             assert len(pw) == len(pg), mode
             for w, g in zip(pw, pg):
@@ -66,11 +71,11 @@ def test_text_and_boxes_identical_on_full_size_pages(readers_trained, oracle_tra
                 if w[1] != g[1]:
                     bad_text.append((w[1], g[1]))
                 else:
-                    worst_conf = max(worst_conf, abs(float(w[2]) - g[2]) / max(float(w[2]), 1e-3))
-        report[mode] = (len(bad_text), round(worst_conf, 5))
+                    conf_err.append(abs(float(w[2]) - g[2]) / max(float(w[2]), 1e-3))
+        report[mode] = (len(bad_text), float(np.max(conf_err)), float(np.median(conf_err)))
         assert len(bad_text) <= MAX_TEXT_MISMATCH[mode], (mode, bad_text[:4])
-        assert worst_conf <= {"bf16": 0.15, "fp16": 0.03, "exact": 1e-3}[mode], (mode, worst_conf)
-    print(f"{n_boxes} boxes; per mode (boxes whose text differs from the fp32 oracle, max relative confidence error): {report}")
+        assert np.max(conf_err) <= CONF_BOUND[mode][0] and np.median(conf_err) <= CONF_BOUND[mode][1], (mode, report[mode])
+    print(f"{n_boxes} boxes; per mode (boxes whose text differs from the fp32 oracle, max / median relative confidence error): {report}")
 
 
 @pytest.mark.gpu
@@ -96,8 +101,8 @@ def test_argmax_flips_only_where_the_oracle_margin_is_below_the_noise(readers_tr
         margin = (srt[..., -1] - srt[..., -2]) / np.abs(ref).max(axis=(1, 2), keepdims=True)[..., 0]
         steps += margin.size
         g = np.rint((x * 0.5 + 0.5) * 255.0).astype(np.int32)                            # the uint8 levels back (exact: x came from them)
-        inputs = {"bf16": torch.from_numpy(x).to(torch.bfloat16), "fp16": torch.from_numpy(x).to(torch.float16),
-                  "exact": torch.from_numpy((g + 1).astype(np.int16))}
+        inputs = {"bf16": torch.from_numpy(x).to(torch.bfloat16), "mixed": torch.from_numpy(x).to(torch.float16),
+                  "fp16": torch.from_numpy(x).to(torch.float16), "exact": torch.from_numpy((g + 1).astype(np.int16))}
         for mode, t in inputs.items():
             r = readers_trained[mode]
             T = W // 4 - 1
@@ -122,9 +127,60 @@ def test_batched_entry_equals_single_pages_in_every_mode(readers_trained):
     from bb_ocr_amd import synth
 
     small = [synth.page(300 + i, width=448, height=288, lines=6, margin=24, colour=bool(i & 1))[0] for i in range(3)]
-    for mode in ("bf16", "fp16"):
+    for mode in ("bf16", "mixed"):
         r = readers_trained[mode]
         for group in (pages, small):
             single = [r.readtext(im) for im in group]
             assert r.readtext_batched(group) == single, mode
             assert all(len(s) >= 4 for s in single)
+
+
+PHOTOS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "photos")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["IMG_9685.JPG", "IMG_9684.JPG"])
+def test_reference_photographs_through_the_zero_edit_hook(name, states_trained, oracle_trained, tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: a real book-cover JPEG through the reference's OWN lines -- `import easyocr` (enhanced_extractor.py:19),
+    `easyocr.Reader(["en"], gpu=use_gpu)` (:153), `reader.readtext(path, paragraph=False, batch_size=1, workers=0)` (:520),
+    `" ".join(r[1] for r in results)` (:521) -- after bb_ocr_amd.install(), with the weights found as checkpoint files where upstream
+    keeps them.  The photographs (pipeline_demo/books/2a, inputs of ocr_comparison_IMG_968{4,5}.json) give the box stages what the
+    PIL-font pages never do: ragged / slanted / huge / tiny components, free (rotated) boxes, the off-grid 1014x971 canvas, libjpeg's Y
+    plane as the grey image.  Against OracleReader.readtext(path): boxes identical (grouped and free), text identical in the default
+    (mixed) and exact modes, joined strings equal."""
+    import sys
+
+    import bb_ocr_amd
+
+    cs, rs = states_trained
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(str(tmp_path), "craft_mlt_25k.pth"))
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, os.path.join(str(tmp_path), "english_g2.pth"))
+    monkeypatch.setenv("BBOCR_WEIGHTS_DIR", str(tmp_path))
+    path = os.path.join(PHOTOS, name)
+    want = oracle_trained.readtext(path)
+    n_free = sum(not isinstance(w[0][0][0], (int, np.integer)) for w in want)          # free boxes keep upstream's float corners
+    assert len(want) >= 5
+    prev = sys.modules.get("easyocr")
+    try:
+        bb_ocr_amd.install()
+        import easyocr                                                       # enhanced_extractor.py:19
+
+        for precision in ("mixed", "exact"):
+            monkeypatch.setenv("BBOCR_PRECISION", precision)
+            reader = easyocr.Reader(["en"], gpu=True)                       # :153
+            try:
+                results = reader.readtext(path, paragraph=False, batch_size=1, workers=0)      # :520
+                text = " ".join(r[1] for r in results)                      # :521
+            finally:
+                reader.close()
+            assert len(results) == len(want), precision
+            for g, w in zip(results, want):
+                assert _same_box(g[0], w[0]), (precision, g[0], w[0])
+            assert [g[1] for g in results] == [w[1] for w in want], precision
+            assert text == " ".join(w[1] for w in want)
+            if precision == "exact":
+                assert all(abs(g[2] - float(w[2])) <= 1e-3 * max(float(w[2]), 1e-3) for g, w in zip(results, want))
+    finally:
+        bb_ocr_amd.uninstall()
+        assert sys.modules.get("easyocr") is prev
+    print(f"{name}: {len(want)} boxes ({n_free} free / rotated), identical to the oracle's in the mixed and exact modes; text: {text[:80]!r}")

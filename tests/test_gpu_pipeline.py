@@ -105,7 +105,7 @@ def test_heatmap_random_weights_relative(reader):
     from oracle import pipeline
 
     cs, rs = weights.synthetic_craft_state(3), weights.synthetic_crnn_state(3)
-    r = bb_ocr_amd.Reader(["en"], weights=(cs, rs))
+    r = bb_ocr_amd.Reader(["en"], weights=(cs, rs), precision="bf16")
     ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
     img = synth.page(5, width=352, height=224, lines=4, margin=24)[0]       # 224 = 7*32: odd tile counts at every level
     heat, _ = r.heatmap_device(torch.from_numpy(img[None]).cuda())
@@ -169,7 +169,7 @@ def test_reader_from_checkpoint_directory(states, reader, tmp_path):
     cs, rs = states
     torch.save({("module." + k): torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(str(tmp_path), "craft_mlt_25k.pth"))
     torch.save({"state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}}, os.path.join(str(tmp_path), "english_g2.pth"))
-    r2 = bb_ocr_amd.Reader(["en"], gpu=True, model_storage_directory=str(tmp_path))
+    r2 = bb_ocr_amd.Reader(["en"], gpu=True, model_storage_directory=str(tmp_path), precision="bf16")
     try:
         for seed in (5, 6):
             img = synth.page(seed, width=384, height=256, lines=5, margin=24, colour=bool(seed & 1))[0]
@@ -446,7 +446,7 @@ def test_full_size_batch_properties(reader):
         assert reader.readtext_device(rgb[i:i + 1])[0] == out[i], f"page {i}: batch of 1 differs from batch of 64"
     assert reader.readtext_device(rgb[5:30]) == out[5:30]                        # 25 pages: schedule [17, 8]
     heat, ratio = reader.heatmap_device(rgb)
-    other = bb_ocr_amd.Reader(["en"], weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), det_sub_batch=8)
+    other = bb_ocr_amd.Reader(["en"], weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), det_sub_batch=8, precision="bf16")
     heat8, ratio8 = other.heatmap_device(rgb)
     assert ratio == ratio8 and torch.equal(heat, heat8)
     # every word the renderer drew is found exactly once on every page (boxes are word-level for this detector)
@@ -541,7 +541,7 @@ def test_context_teardown_returns_device_memory(states):
     img = synth.page(901, width=640, height=384, lines=5, margin=24)[0]
 
     def cycle():
-        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states)
+        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="bf16")
         assert r.readtext(img) and r.readtext(img, decoder="beamsearch") and r.readtext(img, rotation_info=[90, 180, 270])
         r.close()
 
@@ -566,7 +566,7 @@ def test_sequence_pass_budgets_do_not_change_results(states, reader):
     want = reader.readtext_device(rgb)
     assert sum(len(p) for p in want[16:]) > sum(len(p) for p in want[:16])
     for cols in (1500, 12000, 40000, 90000, 105000, 118000, 130000, 160000):
-        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, rec_max_cols=cols)
+        r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, rec_max_cols=cols, precision="bf16")
         assert r.readtext_device(rgb) == want, f"rec_max_cols={cols}"
         r.close()
 

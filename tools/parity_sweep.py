@@ -26,7 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pages", type=int, default=64)
-    ap.add_argument("--modes", default="bf16,fp16,exact")
+    ap.add_argument("--first", type=int, default=0, help="index of the first page (seed 1234 + first); bench.py uses 0..7")
+    ap.add_argument("--modes", default="bf16,mixed,fp16,exact")
     ap.add_argument("--config", default="p1", choices=("p1", "a4"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "text_parity.json"))
     args = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
     cs, rs, label = bench.load_states("trained")
     cw, ch, _, cl, _, _, _ = bench.CONFIGS[args.config]
     kw = bench.page_kwargs(args.config, cw, ch, cl)
-    rendered = [synth.page(1234 + i, colour=bool(i & 1), **kw) for i in range(args.pages)]
+    rendered = [synth.page(1234 + args.first + i, colour=bool((args.first + i) & 1), **kw) for i in range(args.pages)]
     pages = [p[0] for p in rendered]
     ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
     t0 = time.time()
@@ -69,7 +70,7 @@ def main():
                 read += 1
     mg = np.array(margins)
     hist_edges = [0, 1e-3, 2e-3, 4e-3, 8e-3, 1.6e-2, 3e-2, 6e-2, 0.12, 0.25, 1.0]
-    report = {"pages": args.pages, "config": args.config, "boxes": n_boxes, "weights": label,
+    report = {"pages": args.pages, "first_page": args.first, "config": args.config, "boxes": n_boxes, "weights": label,
               "oracle_seconds": time.time() - t0,
               "oracle_reads_ground_truth_words": f"{read}/{gt_words}",
               "oracle_confidence_quantiles": {q: float(np.quantile([float(c) for w in want for _, _, c in w], float(q))) for q in ("0.01", "0.1", "0.5")},
@@ -87,16 +88,18 @@ def main():
             got = r.readtext_device(rgb)
             dt = time.time() - t1
             p = bench.parity(want, got, mode)
-            diffs, conf_err = [], 0.0
+            diffs, conf_err, conf_all = [], 0.0, []
             k = 0
             for pw, pg in zip(want, got):
                 for w, g in zip(pw, pg):
                     if w[1] != g[1] and len(diffs) < 40:
                         diffs.append({"oracle": w[1], "gpu": g[1], "oracle_min_margin": margins[k] if k < len(margins) else None, "oracle_conf": float(w[2]), "gpu_conf": float(g[2])})
-                    if w[1] == g[1]:
-                        conf_err = max(conf_err, abs(float(w[2]) - float(g[2])) / max(float(w[2]), 1e-3))
+                    if w[1] == g[1] and np.array_equal(np.asarray(w[0], dtype=np.float64), np.asarray(g[0], dtype=np.float64)):
+                        conf_all.append(abs(float(w[2]) - float(g[2])) / max(float(w[2]), 1e-3))
+                        conf_err = max(conf_err, conf_all[-1])
                     k += 1
-            p.update(ms_per_batch=dt * 1e3, differing_boxes=diffs, max_relative_confidence_error_on_equal_texts=conf_err,
+            p.update(relative_confidence_error_quantiles={q: float(np.quantile(conf_all, float(q))) for q in ("0.5", "0.9", "0.99", "1.0")} if conf_all else None,
+                     ms_per_batch=dt * 1e3, differing_boxes=diffs, max_relative_confidence_error_on_equal_boxes_and_texts=conf_err,
                      box_count_equal=bool(all(len(a) == len(b) for a, b in zip(want, got))))
             report["modes"][mode] = p
             print(f"[{mode}] boxes identical {p['boxes_identical']}, texts identical {p['texts_identical']}, pages identical {p['pages_identical']}; "
