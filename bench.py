@@ -165,7 +165,7 @@ def run_leg(name, config, precision, steps, states, args):
     t_leg = time.perf_counter()
     reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision=precision)
     try:
-        uniq = render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else args.unique)
+        uniq = render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else cb)
         rgb = torch.from_numpy(np.stack([uniq[i % len(uniq)] for i in range(cb)])).cuda()
         dt, stage, out = timed_steps(reader, rgb, steps, 1, tag=f"[leg {name}] ")
         rf = roofline(reader, config, cb, steps)
@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="p1", help="p1 = BASELINE.json configs[2]/[3] (the metric's workload), a4 = configs[4]")
     ap.add_argument("--batch", type=int, default=0, help="pages per GPU per step (0 = the config's)")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic pages rendered per rank (tiled to --batch)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic pages rendered per rank, tiled to --batch (0 = --batch: every page of the batch is its own page)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
@@ -207,6 +207,7 @@ def main():
     args.width, args.height = args.width or cw, args.height or ch
     args.batch, args.lines = args.batch or cb, args.lines or cl
     args.precision = args.precision or cprec
+    args.unique = args.unique or args.batch
 
     import numpy as np
     import torch

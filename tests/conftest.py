@@ -115,6 +115,27 @@ def readers_trained(states_trained):
         r.close()
 
 
+def noise_sensitive_craft(seed=11):
+    """A NOISE-SENSITIVE detector: every layer of the trunk contributes to every heat-map pixel.
+    synthetic_craft_state with conv_cls.8 rescaled (exactly: it is a linear 1x1 layer) so the maps of a synthetic page span the thresholds:
+    region map mean 0.30 / std 0.20, affinity map mean 0.20 / std 0.15 -- about a fifth of the pixels above 0.4, in many ragged components."""
+    import torch
+
+    from bb_ocr_amd import synth, weights
+    from oracle import pipeline
+
+    cs = weights.synthetic_craft_state(seed)
+    rs = weights.synthetic_crnn_state(seed)
+    ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
+    img = synth.page(900, width=640, height=480, lines=10, margin=24, colour=True)[0]
+    st, sl, _ = ref.heatmap(img)
+    for ch, (m, mean, std) in enumerate(((st, 0.30, 0.20), (sl, 0.20, 0.15))):
+        g = std / max(float(m.std()), 1e-12)
+        cs["conv_cls.8.weight"][ch] *= g
+        cs["conv_cls.8.bias"][ch] = mean + (cs["conv_cls.8.bias"][ch] - float(m.mean())) * g
+    return cs, rs
+
+
 class LogitTap:
     """Wraps an OracleReader so that the logits of every recogniser call are kept: the top-2 margins tell where an arg-max is
     numerically decidable (a character may differ from the oracle only where the oracle's own margin is below the noise
