@@ -6,7 +6,9 @@ import bb_ocr_amd
 from bb_ocr_amd import synth, weights
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-r = bb_ocr_amd.Reader(["en"], weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), det_sub_batch=n)
+sub = int(sys.argv[3]) if len(sys.argv) > 3 else n          # pages per detector pass (default: all n in one pass)
+r = bb_ocr_amd.Reader(["en"], weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), det_sub_batch=sub,
+                      precision=os.environ.get("BBOCR_PRECISION", "bf16"))
 pg = synth.page(1234)[0]
 rgb = torch.from_numpy(np.stack([pg] * n)).cuda()
 for _ in range(reps):
