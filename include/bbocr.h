@@ -44,17 +44,18 @@ typedef struct bbocr_config {
     int precision;      /* arithmetic of the two networks (fixed per context: the weights are packed for it at bbocr_load_weights):
                          *   BBOCR_PREC_BF16  (0) bf16 MFMA operands and stored activations, fp32 accumulation;
                          *   BBOCR_PREC_FP16  (1) the same kernels on IEEE fp16 operands (v_mfma_f32_16x16x32_f16): 8x finer rounding,
-                         *                        range 6e-8 .. 65504 -- BASELINE.json configs[4] ("fp16 MFMA conv path");
+                         *                        range 6e-8 .. 65504 -- BASELINE.json configs[4] ("fp16 MFMA conv path"), and what the Python host
+                         *                        (bb_ocr_amd.Reader) selects unless told otherwise: boxes and strings equal to the fp32 CPU path's
+                         *                        on every input class measured;
                          *   BBOCR_PREC_EXACT (2) detector as FP16; recogniser in split fp16: every activation and weight is a pair
                          *                        hi + lo of fp16 values (22 significand bits) and every product runs as the three MFMA
                          *                        terms hi*hi + lo*hi + hi*lo accumulated in fp32, LSTM state and gates in fp32 --
-                         *                        the mode whose decoded TEXT equals the fp32 CPU path's (3x the recogniser's MFMA work);
-                         *   BBOCR_PREC_MIXED (3) detector as BF16, recogniser as FP16: the cheapest arithmetic that decoded all of 2,000+
-                         *                        boxes of the 1280x960 workload to the fp32 CPU path's strings with identical boxes
-                         *                        (profiles/r03_text_parity.json) -- bf16 keeps the detector's clock (fp16 operands
-                         *                        toggle more bits under the power limit), the recogniser's 8x finer rounding keeps
-                         *                        its arg-max.
-                         *                        What the Python host (bb_ocr_amd.Reader) selects unless told otherwise.
+                         *                        additionally reproduces the CONFIDENCES of the fp32 CPU path (1e-5; 3x the recogniser's MFMA work);
+                         *   BBOCR_PREC_MIXED (3) detector as BF16, recogniser as FP16: 1.6 % faster than FP16 and as exact on binary-ink pages
+                         *                        (2,051 of 2,051 boxes and strings of the 1280x960 workload equal the fp32 CPU path's,
+                         *                        profiles/r03_text_parity.json): bf16 keeps the detector's clock (fp16 operands
+                         *                        toggle more bits under the power limit); on continuous-tone images its bf16
+                         *                        heat-map flips a few threshold decisions (3 of 110 boxes on the reference's images).
                          * Any other value: bbocr_create returns BBOCR_ERR_ARG. */
     int reserved[4];
 } bbocr_config;
