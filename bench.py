@@ -10,10 +10,11 @@ synthetic 1280x960 pages per GPU, pages already resident in HBM.  Workload = BAS
 64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL) -- at N = 8
 that is BASELINE.json configs[3] (512 pages sharded across 8 MI355X).  `--config a4` runs configs[4]'s per-GPU share
 instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision; the p1
-default is "fp16" (both networks on v_mfma_f32_16x16x32_f16), the library's default: the cheapest arithmetic whose boxes AND decoded
-strings equalled the fp32 CPU path's on everything measured (2,051 boxes of this workload, dense A4 scans, the reference's real images:
-tools/parity_sweep.py, profiles/r03_text_parity*.json).  "mixed" (bf16 detector + fp16 recogniser) is 1.6 % faster and just as exact on
-THESE pages, but its bf16 detector flips threshold decisions on continuous-tone images; plain bf16 also gets 1 string of 2,051 wrong.
+default is "mixed" (bf16 detector + fp16 recogniser): the cheapest arithmetic whose boxes AND decoded strings equalled the fp32 CPU
+path's on all 2,051 boxes of 64 distinct pages of THIS workload (tools/parity_sweep.py, profiles/r03_text_parity.json; plain bf16 gets
+1 string of 2,051 wrong), re-checked in every run by `parity_in_run`.  The LIBRARY's default is "fp16" (2-3 % slower: fp16 operands cost
+detector clock under the power limit): continuous-tone inputs (dense A4 scans, the reference's real images) need the fp16 detector
+(DESIGN.md section 4); its rate on this workload is `legs.fp16`.
 
 Weights: the designed detector (bb_ocr_amd.weights.designed_craft_state) and the recogniser checkpoint trained on these
 synthetic pages (tests/golden/crnn_synth_fp16.npz, tests/golden/train_crnn.py) -- a recogniser that reads the pages has the
@@ -26,7 +27,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   parity_in_run -- the SAME pages the CPU oracle just read, compared with what the timed GPU step returned for them:
                    boxes identical n/m, texts identical n/m.
   legs          -- N=1 only, after the timed region: a few steps each of the other driver-visible modes
-                   (`--precision mixed`, `--precision exact`, `--config a4`), own readers, own roofline fractions.
+                   (`--precision fp16` = the library default, `--precision exact`, `--config a4`), own readers, own roofline fractions.
   N > 1         -- ranks_seen, devices (per-rank PCI bus id / uuid, all-gathered; must be distinct under nccl),
                    weights_broadcast_ok (a failed broadcast is fatal unless --allow-local-weights).
 """
@@ -44,7 +45,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
 CRAFT_GFLOP_PER_PAGE = {"p1": 874.22, "a4": 3322.03}  # 1280x960 page / A4@300dpi on the 2560 canvas
 CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, line pitch, precision, workload label)
-    "p1": (1280, 960, 64, 24, 38, "fp16", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
+    "p1": (1280, 960, 64, 24, 38, "mixed", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
     "a4": (2480, 3504, 16, 110, 31, "fp16", "A4@300dpi 2480x3504 dense-text scans, fp16 MFMA conv path, 16 pages per GPU "
                                            "(BASELINE.json configs[4]: batch=128 on 8 GPUs)"),
 }
@@ -196,7 +197,7 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
-    ap.add_argument("--legs", default="mixed,exact,a4", help="N=1: extra modes run after the timed region (comma list of mixed, exact, a4; '' = none)")
+    ap.add_argument("--legs", default="fp16,exact,a4", help="N=1: extra modes run after the timed region (comma list of fp16, mixed, bf16, exact, a4; '' = none)")
     ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 renders every rank's pages and scatters them (dist.scatter_pages: grouped "
@@ -356,7 +357,7 @@ def main():
         torch.cuda.empty_cache()
         legs = {}
         for name in [s for s in args.legs.split(",") if s]:
-            if name in ("exact", "mixed") and not (args.config == "p1" and args.precision == name):
+            if name in ("exact", "mixed", "fp16", "bf16") and not (args.config == "p1" and args.precision == name):
                 legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), args)
             elif name == "a4" and args.config != "a4":
                 legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs), args)
