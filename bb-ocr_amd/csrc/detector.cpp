@@ -250,8 +250,8 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
     if (d.th <= 0 || d.tw <= 0) fail(BBOCR_ERR_ARG, "page collapses to zero size");
     // Pages per detector pass.  Explicit det_sub_batch: uniform passes of that size.  Auto: passes as large as a 96 GB
     // activation arena allows (sized by a dry run on one page; at most 64 pages), and -- when the caller overlaps box
-    // extraction with the next pass (readtext_batch) -- a short last pass of 8 pages, because only the LAST pass's
-    // CCL + host geometry is exposed: 64 pages run as [56, 8].
+    // extraction with the next pass (readtext_batch) -- a short last pass of 8 pages (of 1280x960; fewer, larger ones by pixel count),
+    // because only the LAST pass's CCL + host geometry is exposed: 64 pages run as [56, 8], 16 A4@300dpi scans as [14, 2].
     std::vector<int> passes;
     if (c->cfg.det_sub_batch > 0) {
         for (int b0 = 0; b0 < B; b0 += c->cfg.det_sub_batch) passes.push_back(std::min(c->cfg.det_sub_batch, B - b0));
@@ -260,8 +260,11 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
         craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
         const size_t per_page = std::max<size_t>(c->arena.off, 1);
         const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)96 << 30) / per_page));
-        static const int tail_pages = diag_knob("BBOCR_DET_TAIL", 8);   // A/B knob
-        const int tail = (after_sub && B >= 24 && cap > tail_pages && tail_pages > 0) ? tail_pages : 0;
+        static const int tail_knob = diag_knob("BBOCR_DET_TAIL", 8);   // A/B knob: tail length in 1280x960-page equivalents
+        // pages larger than 1280x960 (an A4@300dpi canvas is 3.8 of them) count by their pixels: 16 A4 scans run as [14, 2]
+        const double equiv = std::max(1.0, (double)d.th * d.tw / (960.0 * 1280.0));
+        const int tail_pages = tail_knob > 0 ? std::max(1, (int)std::lround(tail_knob / equiv)) : 0;
+        const int tail = (after_sub && B * equiv >= 24.0 && cap > tail_pages && B > tail_pages && tail_pages > 0) ? tail_pages : 0;
         const int body = B - tail, nbig = cdiv(body, cap);
         for (int i = 0; i < nbig; ++i) passes.push_back(body / nbig + (i < body % nbig ? 1 : 0));
         if (tail) passes.push_back(tail);
