@@ -398,6 +398,16 @@ def test_error_paths_raise(reader):
     with pytest.raises(ValueError):
         reader.boxes_from_heatmap(torch.zeros((1, 32, 48, 2), dtype=torch.float16, device="cuda"), 1.0)
     assert reader.readtext_device(ok) == [[]]
+    # a context's packed weights (and with them the blob layout its peers import) are fixed: a second load is refused, not appended
+    from bb_ocr_amd import weights
+
+    arr, keep = weights.to_descs(weights.synthetic_crnn_state(5))
+    with pytest.raises(RuntimeError, match="already loaded"):
+        reader._check(reader._lib.bbocr_load_weights(reader._h, 1, arr, len(arr)))
+    with pytest.raises(RuntimeError, match="already"):
+        reader._check(reader._lib.bbocr_alloc_weights(reader._h, 0))
+    with pytest.raises(ValueError):
+        __import__("bb_ocr_amd").Reader(["en"], weights="empty", precision="fp8")
 
 
 def test_hip_path_against_committed_golden(reader):
