@@ -141,62 +141,77 @@ REAL_IMAGES = ["photos/IMG_9685.JPG", "photos/IMG_9684.JPG",                    
                "ref_images/book5_preprocessed.png", "ref_images/book6_preprocessed.png"]   # ... of ocr_comparison_book{1,2,4,5,6}.json (grey PNGs)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", REAL_IMAGES)
-def test_reference_photographs_through_the_zero_edit_hook(name, states_trained, oracle_trained, tmp_path, monkeypatch):
-    """BASELINE.json configs[0]: a real book-cover JPEG through the reference's OWN lines -- `import easyocr` (enhanced_extractor.py:19),
-    `easyocr.Reader(["en"], gpu=use_gpu)` (:153), `reader.readtext(path, paragraph=False, batch_size=1, workers=0)` (:520),
-    `" ".join(r[1] for r in results)` (:521) -- after bb_ocr_amd.install(), with the weights found as checkpoint files where upstream
-    keeps them.  The photographs (pipeline_demo/books/2a, inputs of ocr_comparison_IMG_968{4,5}.json) give the box stages what the
-    PIL-font pages never do: ragged / slanted / huge / tiny components, free (rotated) boxes, the off-grid 1014x971 canvas, libjpeg's Y
-    plane as the grey image; the five pre-processed book covers are the images the reference itself fed to EasyOCR for
-    ocr_comparison_book*.json (single-channel PNGs, 322x439 .. 1050x1312: CLAHE-sharpened real print, every size off the 32-pixel grid).
-    Against OracleReader.readtext(path): boxes identical (grouped and free), texts identical, joined strings equal in the fp16 and exact
-    modes (fp16 detector); the mixed mode (bf16 detector) is measured and bounded."""
+@pytest.fixture(scope="module")
+def hook_readers(states_trained, tmp_path_factory):
+    """The reference's own construction lines, once per precision: `import easyocr` (enhanced_extractor.py:19) after bb_ocr_amd.install(),
+    `easyocr.Reader(["en"], gpu=use_gpu)` (:153) with the weights found as checkpoint files where upstream keeps them (BBOCR_WEIGHTS_DIR)
+    and the precision taken from the environment -- the call site passes neither."""
     import sys
 
     import bb_ocr_amd
 
+    d = tmp_path_factory.mktemp("weights")
     cs, rs = states_trained
-    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(str(tmp_path), "craft_mlt_25k.pth"))
-    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, os.path.join(str(tmp_path), "english_g2.pth"))
-    monkeypatch.setenv("BBOCR_WEIGHTS_DIR", str(tmp_path))
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()}, os.path.join(str(d), "craft_mlt_25k.pth"))
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, os.path.join(str(d), "english_g2.pth"))
+    prev = sys.modules.get("easyocr")
+    saved = {k: os.environ.get(k) for k in ("BBOCR_WEIGHTS_DIR", "BBOCR_PRECISION")}
+    readers = {}
+    try:
+        os.environ["BBOCR_WEIGHTS_DIR"] = str(d)
+        bb_ocr_amd.install()
+        import easyocr                                                       # enhanced_extractor.py:19
+
+        for precision in ("fp16", "exact", "mixed"):
+            os.environ["BBOCR_PRECISION"] = precision
+            readers[precision] = easyocr.Reader(["en"], gpu=True)           # :153
+        yield readers
+    finally:
+        for r in readers.values():
+            r.close()
+        bb_ocr_amd.uninstall()
+        assert sys.modules.get("easyocr") is prev
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REAL_IMAGES)
+def test_reference_photographs_through_the_zero_edit_hook(name, hook_readers, oracle_trained):
+    """BASELINE.json configs[0]: a real book-cover JPEG through the reference's OWN lines -- `import easyocr` (enhanced_extractor.py:19),
+    `easyocr.Reader(["en"], gpu=use_gpu)` (:153, the `hook_readers` fixture), `reader.readtext(path, paragraph=False, batch_size=1,
+    workers=0)` (:520), `" ".join(r[1] for r in results)` (:521) -- after bb_ocr_amd.install().  The photographs (pipeline_demo/books/2a,
+    inputs of ocr_comparison_IMG_968{4,5}.json) give the box stages what the PIL-font pages never do: ragged / slanted / huge / tiny
+    components, free (rotated) boxes, the off-grid 1014x971 canvas, libjpeg's Y plane as the grey image; the five pre-processed book covers
+    are the images the reference itself fed to EasyOCR for ocr_comparison_book*.json (single-channel PNGs, 322x439 .. 1050x1312:
+    CLAHE-sharpened real print, every size off the 32-pixel grid).  Against OracleReader.readtext(path): boxes identical (grouped and free),
+    texts identical, joined strings equal in the fp16 and exact modes (fp16 detector); the mixed mode (bf16 detector) is measured and bounded."""
     path = os.path.join(GOLDEN, name)
     want = oracle_trained.readtext(path)
     n_free = sum(not isinstance(w[0][0][0], (int, np.integer)) for w in want)          # free boxes keep upstream's float corners
     assert len(want) >= 3
-    prev = sys.modules.get("easyocr")
-    try:
-        bb_ocr_amd.install()
-        import easyocr                                                       # enhanced_extractor.py:19
-
-        report = {}
-        for precision in ("fp16", "exact", "mixed"):
-            monkeypatch.setenv("BBOCR_PRECISION", precision)
-            reader = easyocr.Reader(["en"], gpu=True)                       # :153
-            try:
-                results = reader.readtext(path, paragraph=False, batch_size=1, workers=0)      # :520
-                text = " ".join(r[1] for r in results)                      # :521
-            finally:
-                reader.close()
-            if precision == "mixed":
-                # bf16 DETECTOR on continuous-tone content: a few of the ~1e6 threshold decisions sit inside bf16's 0.008 heat-map error
-                # (tools/flip_report.py: 8 flips on the two photographs), so a component can gain / lose a pixel row or drop below the 0.7
-                # peak test.  Measured: 6 of these 7 images identical, one box of 37 lost on book6.  Reported, bounded, not hidden.
-                wb = {tuple(np.asarray(w[0], dtype=np.float64).reshape(-1).tolist()): w[1] for w in want}
-                same = sum(wb.get(tuple(np.asarray(g[0], dtype=np.float64).reshape(-1).tolist())) == g[1] for g in results)
-                report[precision] = f"{same}/{len(want)} boxes with identical coordinates and text"
-                assert abs(len(results) - len(want)) <= 2 and same >= 0.9 * len(want), (precision, report)
-                continue
-            assert len(results) == len(want), precision
-            for g, w in zip(results, want):
-                assert _same_box(g[0], w[0]), (precision, g[0], w[0])
-            assert [g[1] for g in results] == [w[1] for w in want], precision
-            assert text == " ".join(w[1] for w in want)
-            if precision == "exact":
-                assert all(abs(g[2] - float(w[2])) <= 1e-3 * max(float(w[2]), 1e-3) for g, w in zip(results, want))
-            report[precision] = "identical"
-    finally:
-        bb_ocr_amd.uninstall()
-        assert sys.modules.get("easyocr") is prev
+    report = {}
+    for precision in ("fp16", "exact", "mixed"):
+        results = hook_readers[precision].readtext(path, paragraph=False, batch_size=1, workers=0)      # :520
+        text = " ".join(r[1] for r in results)                      # :521
+        if precision == "mixed":
+            # bf16 DETECTOR on continuous-tone content: a few of the ~1e6 threshold decisions sit inside bf16's 0.008 heat-map error
+            # (tools/flip_report.py: 8 flips on the two photographs), so a component can gain / lose a pixel row or drop below the 0.7
+            # peak test.  Measured: 6 of these 7 images identical, 3 boxes of 37 differ on book6.  Reported, bounded, not hidden.
+            wb = {tuple(np.asarray(w[0], dtype=np.float64).reshape(-1).tolist()): w[1] for w in want}
+            same = sum(wb.get(tuple(np.asarray(g[0], dtype=np.float64).reshape(-1).tolist())) == g[1] for g in results)
+            report[precision] = f"{same}/{len(want)} boxes with identical coordinates and text"
+            assert abs(len(results) - len(want)) <= 2 and same >= 0.9 * len(want), (precision, report)
+            continue
+        assert len(results) == len(want), precision
+        for g, w in zip(results, want):
+            assert _same_box(g[0], w[0]), (precision, g[0], w[0])
+        assert [g[1] for g in results] == [w[1] for w in want], precision
+        assert text == " ".join(w[1] for w in want)
+        if precision == "exact":
+            assert all(abs(g[2] - float(w[2])) <= 1e-3 * max(float(w[2]), 1e-3) for g, w in zip(results, want))
+        report[precision] = "identical"
     print(f"{name}: {len(want)} boxes ({n_free} free / rotated) vs the oracle: {report}")
