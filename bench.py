@@ -157,8 +157,9 @@ def device_identity(local_rank):
     return ident
 
 
-def run_leg(name, config, precision, steps, states, args):
-    """One of the other driver-visible modes on this card, after the main timed region: own reader, own pages."""
+def run_leg(name, config, precision, steps, states, pages=None):
+    """One of the other driver-visible modes on this card, after the main timed region: own reader; `pages` = the main run's rendered
+    pages when the leg reads the same workload (else its own are rendered)."""
     import numpy as np
     import torch
 
@@ -168,7 +169,7 @@ def run_leg(name, config, precision, steps, states, args):
     t_leg = time.perf_counter()
     reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision=precision)
     try:
-        uniq = render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else cb)
+        uniq = pages if pages is not None else render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else cb)
         rgb = torch.from_numpy(np.stack([uniq[i % len(uniq)] for i in range(cb)])).cuda()
         dt, stage, out = timed_steps(reader, rgb, steps, 1, tag=f"[leg {name}] ")
         rf = roofline(reader, config, cb, steps)
@@ -358,9 +359,10 @@ def main():
         legs = {}
         for name in [s for s in args.legs.split(",") if s]:
             if name in ("exact", "mixed", "fp16", "bf16") and not (args.config == "p1" and args.precision == name):
-                legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), args)
+                same = args.config == "p1" and (args.width, args.height, args.lines, args.batch) == CONFIGS["p1"][:2] + (CONFIGS["p1"][3], CONFIGS["p1"][2])
+                legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), uniq if same else None)
             elif name == "a4" and args.config != "a4":
-                legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs), args)
+                legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs))
             if legs:
                 log(f"leg {name}: {list(legs.values())[-1]['value']:.1f} images/s")
         if legs:
