@@ -332,11 +332,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MF
 // result is bit-identical to pooling the finished values (conv_epilogue) -- then ONE bias / ReLU / pack per pooled value instead of
 // four, and each lane of a pixel pair finishes only the run it stores (even lane run 0, odd lane run 1: whole 128-byte lines).  The kernel
 // carries none of the shared epilogue's variants: it was vector-issue bound with ~300 of its 1,170 VALU instructions per wave in here.
+// (cout_base: first cout of the wave's 64 -- 0 in the fused conv1_2 launch, nt * BN + wn * 64 when the 128-cout trunk layers conv3_3 /
+// conv4_3 take this path: 16 x 16 tiles, only the pooled tensor kept, see launch_dma's `lean` rule)
 template <int EL, int MF>
-__device__ __forceinline__ void conv_epilogue_pool2x2_lean(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int oy0, int ox0, int wm, int lane) {
+__device__ __forceinline__ void conv_epilogue_pool2x2_lean(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int oy0, int ox0, int wm, int lane,
+                                                           int cout_base = 0) {
     static_assert(MF % 2 == 0, "fragment f and f + 1 are the two rows of a pooling window");
     const int g = lane >> 4, pl = lane & 15, odd = pl & 1;
-    const int cout0 = g * 8;
+    const int cout0 = cout_base + g * 8;
     const float sc = a.acc_scale;
     const float floor_v = (a.relu_out || a.pool_relu) ? 0.f : -__builtin_inff();
     float bsel[8];
@@ -363,6 +366,71 @@ __device__ __forceinline__ void conv_epilogue_pool2x2_lean(const ConvArgs& a, f3
         const u32x4 pk = {El<EL>::pack2(o[0], o[1]), El<EL>::pack2(o[2], o[3]), El<EL>::pack2(o[4], o[5]), El<EL>::pack2(o[6], o[7])};
         uint16_t* op = (uint16_t*)a.pool_out + ((size_t)(n * POH + py) * POW + px) * a.pool_cs + cout0 + odd * 32;
         if (py < POH && px < POW) *(u32x4*)op = pk;
+    }
+}
+
+// The plain trunk layer's epilogue -- bias (+ ReLU) -> 16-bit NHWC, all 64 couts of the wave stored -- and nothing else.  The shared
+// epilogue above executes ~1,000 vector instructions per wave behind a k-loop whose co-resident workgroup keeps the SIMD's issue port half
+// busy with MFMAs: 9-15 k cycles during which the workgroup's LDS and registers are held and its slot computes nothing (timing-only
+// ablation, BBOCR_CONV_DBG=8: the pass is 20 % shorter without epilogues, conv2_1 33 %).  Here a value costs one add, half a convert and
+// half an integer max: ReLU is applied to the PACKED pair (both element types are sign-magnitude, so max(int16, 0) == ReLU, and
+// round-then-ReLU == ReLU-then-round bit for bit), bias is a plain add (acc_scale is 1 on this path), interior tiles skip the per-lane
+// bounds tests.  WHOLE: regroup the two 32-byte runs of a pixel across lanes so that every store writes whole 128-byte lines (as above).
+template <int EL, int MF, bool WHOLE>
+__device__ __forceinline__ void conv_epilogue_plain_lean(const ConvArgs& a, f32x4 (&acc)[MF][4], int n, int nt, int oy0, int ox0, int wm, int wn,
+                                                         int fpr, int lane, int BN) {
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    const int g = lane >> 4, pl = lane & 15;
+    const int cout0 = nt * BN + wn * 64 + g * 8;
+    float bs[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + cout0 + h * 32 + q * 4);
+            bs[h * 8 + q * 4 + 0] = b4[0]; bs[h * 8 + q * 4 + 1] = b4[1]; bs[h * 8 + q * 4 + 2] = b4[2]; bs[h * 8 + q * 4 + 3] = b4[3];
+        }
+    const bool relu = a.relu_out != 0;                                               // wave-uniform
+    const bool inside = oy0 + a.TH <= a.OH && ox0 + a.TW <= a.OW;                     // wave-uniform: a tile inside the image needs no per-lane tests
+    const s16x2_t z2 = {0, 0};
+    // element offset of this lane inside a fragment row: WHOLE -> pixel (pl & 7), run (pl >> 3); else pixel pl, run 0 (run 1 = + 32)
+    const size_t lane_off = WHOLE ? (size_t)(pl & 7) * a.out_cs + cout0 + (pl >> 3) * 32 : (size_t)pl * a.out_cs + cout0;
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int F = wm * MF + f;
+        const int fr = F / fpr, fc = F - fr * fpr;
+        const int oy = oy0 + fr, xb = ox0 + fc * 16;
+        unsigned int p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 2 * i;
+            unsigned int q = El<EL>::pack2(acc[f][k >> 2][k & 3] + bs[k], acc[f][(k + 1) >> 2][(k + 1) & 3] + bs[k + 1]);
+            if (relu) q = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, q), z2));
+            p[i] = q;
+        }
+        uint16_t* op = (uint16_t*)a.out + ((size_t)(n * a.OH + oy) * a.OW + xb) * a.out_cs + lane_off;
+        if constexpr (WHOLE) {
+            u32x4 dA, dB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dA[i] = (unsigned)__builtin_amdgcn_update_dpp((int)p[i], (int)p[4 + i], 0x118 /*row_shr:8*/, 0xF, 0xC, false);
+                dB[i] = (unsigned)__builtin_amdgcn_update_dpp((int)p[4 + i], (int)p[i], 0x108 /*row_shl:8*/, 0xF, 0x3, false);
+            }
+            if (inside) {
+                *(u32x4*)op = dA;
+                *(u32x4*)(op + (size_t)8 * a.out_cs) = dB;
+            } else {
+                const int xA = xb + (pl & 7);
+                if (oy < a.OH && xA < a.OW) *(u32x4*)op = dA;
+                if (oy < a.OH && xA + 8 < a.OW) *(u32x4*)(op + (size_t)8 * a.out_cs) = dB;
+            }
+        } else {
+            const u32x4 lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
+            if (inside || (oy < a.OH && xb + pl < a.OW)) {
+                *(u32x4*)op = lo;
+                *(u32x4*)(op + 32) = hi;
+            }
+        }
     }
 }
 
@@ -925,17 +993,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #pragma unroll
             for (int f = 0; f < 4; ++f) bq[f] = pre[f];
         }
+        // (dbg bits 16 / 32: timing-only ablations of a diagnostic build -- the k-loop without its weight / patch DMA, results are garbage)
         if constexpr (Sched::wcnt(MORE, tap) > 0) {
             int slot = wslot + RING - 1;
             if (slot >= RING) slot -= RING;
-            issue_w(wp, slot);
+            if (!CONV_DBG(a, 16)) issue_w(wp, slot);
             wp += WBUF;
         }
         if constexpr (MORE && Sched::pcnt(tap) > 0) {
             constexpr int p0 = Sched::pfirst(tap);
             const int nc = c + 1;
-            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_p(spix[p0 + I], nc, par ^ 1, std::integral_constant<int, p0 + I>{}), ...); }(
-                std::make_integer_sequence<int, Sched::pcnt(tap)>{});
+            if (!CONV_DBG(a, 32))
+                [&]<int... I>(std::integer_sequence<int, I...>) { (issue_p(spix[p0 + I], nc, par ^ 1, std::integral_constant<int, p0 + I>{}), ...); }(
+                    std::make_integer_sequence<int, Sched::pcnt(tap)>{});
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int kyn = (tap + 1) / KS, kxn = (tap + 1) % KS;
@@ -990,7 +1060,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv3x3_dma_kernel(const Conv
 #endif
     if constexpr (FUSE1) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, lane);       // (launch_dma checks its preconditions)
     else if constexpr (EPI == 1) conv_epilogue_post1x1<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, fpr, lane);                  // (launch_dma checks its preconditions)
-    else conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+    else if constexpr (KS == 3 && NF == 4) {
+        // a.lean (set by launch_dma_one when the layer is a plain one, wave-uniform): 1 / 2 = bias (+ ReLU) -> 16-bit stores, whole lines / half lines;
+        // 3 = the pooled-only epilogue of the fused conv1_2 launch on this layer's couts; 0 = the shared epilogue with all its variants
+        if (a.lean == 1) conv_epilogue_plain_lean<EL, MF, true>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN);
+        else if (a.lean == 2) conv_epilogue_plain_lean<EL, MF, false>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN);
+        else if (a.lean == 3) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, cur.n, cur.oy0, cur.ox0, wm, lane, cur.nt * BN + wn * 64);
+        else conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
+    } else conv_epilogue<EL, MF>(a, acc, cur.n, cur.nt, cur.oy0, cur.ox0, wm, wn, fpr, lane, BN, sub, cur.sph, cur.spw);
 #ifdef BBOCR_DIAG
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
 #endif
@@ -1534,6 +1611,14 @@ static hipError_t launch_dma_one(ConvArgs a, int grid, hipStream_t s) {
     const size_t smem = (one_buf && a.nchunks == 1 && !FUSE1) ? smem_max - (size_t)NPS * 64 : smem_max;
     static LdsOptIn attr;
     if (hipError_t e = lds_opt_in(attr, (const void*)k, smem_max); e != hipSuccess) return e;
+    {   // which epilogue (conv_epilogue_plain_lean / conv_epilogue_pool2x2_lean / the shared one): plain layers whose waves store all their 64 couts
+        static const int lean_knob = diag_knob("BBOCR_CONV_LEAN", 1);      // A/B knob: 0 off, 1 whole-line stores, 2 half-line stores (no DPP regroup)
+        a.lean = 0;
+        const bool plain = lean_knob && !FUSE1 && EPI == 0 && KS == 3 && NF == 4 && a.sub == 1 && !a.out_f32 && !a.tail && !a.split_off && !a.addup && !a.post_w &&
+                           a.acc_scale == 1.f && a.cout_store == a.ntiles_n * WN * 64 && a.out_cs % 8 == 0;
+        if (plain && a.pool_mode == 0 && a.out) a.lean = lean_knob == 2 ? 2 : 1;
+        else if (plain && a.pool_mode == 1 && !a.store_full && a.TH == 16 && a.TW == 16 && a.pool_out) a.lean = 3;
+    }
     if (const char* dir = conv_stamps_dir()) {
         static int seq = 0;
         unsigned long long* dev = nullptr;

@@ -50,6 +50,7 @@ struct ConvArgs {
     const float* aux_b;
     float acc_scale;       // accumulators are multiplied by this before the bias (set from ConvPlan::acc_scale by launch_conv; 1 unless
                            // the packed weights carry a power-of-two scale, see the split-fp16 plans)
+    int lean;              // conv3x3_dma_kernel: which epilogue (set by its launcher: 0 shared, 1 / 2 plain lean with whole / half-line stores, 3 pooled lean)
     int split_off;         // > 0 (fp16 element type only): every stored value v goes out as the pair hi = fp16(v) at its channel and
                            // lo = fp16(v - hi) at channel + split_off -- the [hi | lo] activation layout of the exact recogniser mode
 };
