@@ -18,8 +18,9 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
     bbocr_ctx* c = nullptr;
     try {
         c = new bbocr_ctx();
+        c->root = c;
         if (cfg) c->cfg = *cfg;
-        if (c->cfg.precision < BBOCR_PREC_BF16 || c->cfg.precision > BBOCR_PREC_MIXED) {
+        if (c->cfg.precision < BBOCR_PREC_BF16 || c->cfg.precision > BBOCR_PREC_MIXED || c->cfg.call_slots < 0 || c->cfg.call_slots > kMaxSlots) {
             delete c;                      // an unknown value must not silently mean one of the modes
             return BBOCR_ERR_ARG;
         }
@@ -43,71 +44,123 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
     return BBOCR_OK;
 }
 
-void bbocr_destroy(bbocr_ctx* c) {
-    if (!c) return;
-    (void)hipSetDevice(c->cfg.device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+}  // extern "C"
+
+// a further call slot of `root`: own work buffers (grown on first use), side stream and events; weights and compute stream are the root's
+bbocr_ctx* slot_create(bbocr_ctx* root) {
+    bbocr_ctx* s = new bbocr_ctx();
+    s->root = root;
+    s->cfg = root->cfg;
+    static const bool own_stream = (diag_knob("BBOCR_SLOT_OWN_STREAM", 0) != 0);   // A/B knob: concurrent calls on separate compute streams
+    hipError_t e = hipSuccess;
+    if (own_stream) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    else s->stream = root->stream;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        if (own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+        delete s;
+        fail(BBOCR_ERR_HIP, std::string("call slot: ") + hipGetErrorString(e));
+    }
+    s->cur = s->stream;
+    return s;
+}
+
+// per-slot resources (the root is slot 0): everything but the weights and the root's compute stream
+void slot_destroy(bbocr_ctx* c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
     if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
     if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+    if (c->seq_t1) { (void)hipEventDestroy(c->seq_t1); (void)hipEventDestroy(c->seq_t2); }
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
-    free_weights(c);
     DevBuf* bufs[] = {&c->arena.buf, &c->heat, &c->gray, &c->resized, &c->ccl_label, &c->ccl_stat, &c->ccl_slot, &c->ccl_comps, &c->ccl_rowext,
-                      &c->ccl_counters, &c->crop_desc, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
+                      &c->ccl_counters, &c->crop_desc, &c->crop_desc2, &c->crop_scratch, &c->crop_hscratch, &c->crop_wscratch, &c->crop_luts, &c->crop_hist,
                       &c->ctc_idx, &c->ctc_pmax, &c->ctc_out_idx, &c->ctc_out, &c->seq_v, &c->seq_xp, &c->seq_h, &c->seq_lin, &c->seq_logits,
                       &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab, &c->ctc_probs};
     for (DevBuf* b : bufs) b->release();
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->root != c) {
+        if (c->stream && c->stream != c->root->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+    }
+}
+
+// stage times of the call a thread has just finished (bbocr_stage_times): per calling thread, because one context serves several
+namespace {
+struct ThreadTimes { const bbocr_ctx* root = nullptr; float ms[8] = {0}; };
+thread_local ThreadTimes tl_times;
+thread_local std::string tl_err;
+}  // namespace
+void publish_times(const bbocr_ctx* s) {
+    tl_times.root = s->root;
+    memcpy(tl_times.ms, s->times, sizeof(tl_times.ms));
+}
+
+extern "C" {
+
+void bbocr_destroy(bbocr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (bbocr_ctx* s : c->slots) slot_destroy(s);
+    c->slots.clear();
+    free_weights(c);
+    slot_destroy(c);
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
-const char* bbocr_last_error(bbocr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* bbocr_last_error(bbocr_ctx* c) {
+    if (!c) return "null context";
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    tl_err = c->err;                 // a copy per calling thread: another slot may fail while the caller reads
+    return tl_err.c_str();
+}
 
 int bbocr_load_weights(bbocr_ctx* ctx, int which, const bbocr_tensor_desc* descs, int n) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!descs || n <= 0 || (which != 0 && which != 1)) fail(BBOCR_ERR_ARG, "bad weight descriptor table");
         if (which == 0 ? ctx->craft_loaded : ctx->crnn_loaded)
             fail(BBOCR_ERR_STATE, "this network is already loaded: the packed blocks (and the weight blob layout) are fixed per context -- create a new context");
         TensorMap tm(descs, n);
         if (which == 0) load_craft(ctx, tm);
         else load_crnn(ctx, tm);
-    });
+    }, /*exclusive=*/true);
 }
 
 int bbocr_alloc_weights(bbocr_ctx* ctx, int which) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (which != 0 && which != 1) fail(BBOCR_ERR_ARG, "which: 0 = detector, 1 = recogniser");
         if (which == 0 ? ctx->craft_loaded : ctx->crnn_loaded)
             fail(BBOCR_ERR_STATE, "this network is already laid out in this context -- create a new context");
         TensorMap tm;                        // every tensor present, all zeros: lays the packed plans out, bbocr_weights_import fills them
         if (which == 0) load_craft(ctx, tm);
         else load_crnn(ctx, tm);
-    });
+    }, /*exclusive=*/true);
 }
 
 int bbocr_weights_blob_size(bbocr_ctx* ctx, size_t* bytes) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!bytes) fail(BBOCR_ERR_ARG, "null pointer");
         *bytes = weights_blob_bytes(ctx);
-    });
+    }, /*exclusive=*/true);
 }
 
 int bbocr_weights_export(bbocr_ctx* ctx, void* dev_blob, size_t bytes) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_blob) fail(BBOCR_ERR_ARG, "null device pointer");
         weights_export(ctx, dev_blob, bytes);
-    });
+    }, /*exclusive=*/true);
 }
 
 int bbocr_weights_import(bbocr_ctx* ctx, const void* dev_blob, size_t bytes) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_blob) fail(BBOCR_ERR_ARG, "null device pointer");
         weights_import(ctx, dev_blob, bytes);
-    });
+    }, /*exclusive=*/true);
 }
 
 int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio) {
@@ -122,7 +175,7 @@ int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32,
 }
 
 int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, const bbocr_params* p, float* dev_heat_out) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         bbocr_params pp;
         bbocr_default_params(&pp);
         if (p) pp = *p;
@@ -130,14 +183,14 @@ int bbocr_detect(bbocr_ctx* ctx, const uint8_t* dev_rgb, int B, int H, int W, co
         memset(ctx->times, 0, sizeof(ctx->times));
         auto t0 = clk::now();
         detect_impl(ctx, dev_rgb, B, H, W, pp, dev_heat_out);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot_sync(ctx, ctx->stream);
         prof_collect(ctx);
         ctx->times[0] = ctx->times[7] = (float)ms_since(t0);
     });
 }
 
 int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, double ratio, const bbocr_params* p, bbocr_boxlist** out) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         bbocr_params pp;
         bbocr_default_params(&pp);
         if (p) pp = *p;
@@ -153,7 +206,7 @@ int bbocr_boxes(bbocr_ctx* ctx, const float* dev_heat, int B, int h, int w, doub
 
 int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W, const bbocr_boxlist* boxes, const bbocr_params* p,
                     bbocr_result** out) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         bbocr_params pp;
         bbocr_default_params(&pp);
         if (p) pp = *p;
@@ -173,7 +226,7 @@ int bbocr_recognize(bbocr_ctx* ctx, const uint8_t* dev_gray, int B, int H, int W
 
 int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* dev_gray, int B, int H, int W, const bbocr_params* p,
                          bbocr_result** out) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         bbocr_params pp;
         bbocr_default_params(&pp);
         if (p) pp = *p;
@@ -246,7 +299,7 @@ void bbocr_preproc_defaults(bbocr_preproc_params* p, int legacy) {
 
 int bbocr_preprocess_chain(bbocr_ctx* ctx, const uint8_t* dev_bgr, int H, int W, const bbocr_preproc_params* p, uint8_t* dev_out, int* out_h,
                            int* out_w) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         bbocr_preproc_params q;
         bbocr_preproc_defaults(&q, 0);
         if (p) q = *p;
@@ -283,16 +336,16 @@ void bbocr_free_result(bbocr_result* r) {
 }
 
 int bbocr_set_profiling(bbocr_ctx* ctx, int on) {
-    if (!ctx) return BBOCR_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
-    for (int g = 0; g < 2; ++g) { ctx->prof_ms[g] = 0; ctx->prof_flops[g] = 0; ctx->prof_launches[g] = 0; }
-    return BBOCR_OK;
+    return guarded(ctx, [&](bbocr_ctx* c) {
+        c->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        for (int g = 0; g < 2; ++g) { c->prof_ms[g] = 0; c->prof_flops[g] = 0; c->prof_launches[g] = 0; }
+    }, /*exclusive=*/true);
 }
 
 int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, long long* launches) {
     if (!ctx || group < 0 || group > 1) return BBOCR_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
     if (ms) *ms = ctx->prof_ms[group];
     if (flops) *flops = ctx->prof_flops[group];
     if (launches) *launches = ctx->prof_launches[group];
@@ -301,8 +354,7 @@ int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, lon
 
 int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n) {
     if (!ctx || !ms || n <= 0) return BBOCR_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    for (int i = 0; i < n && i < 8; ++i) ms[i] = ctx->times[i];
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = tl_times.root == ctx ? tl_times.ms[i] : 0.f;
     return BBOCR_OK;
 }
 

@@ -4,7 +4,7 @@
 extern "C" {
 
 int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src, int H, int W, uint8_t* dev_dst, int dh, int dw, double param) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_src || !dev_dst || H <= 0 || W <= 0 || dh <= 0 || dw <= 0) fail(BBOCR_ERR_ARG, "bad arguments");
         if (stage != 0 && (dh != H || dw != W)) fail(BBOCR_ERR_ARG, "only stage 0 changes the size");
         const size_t n = (size_t)H * W;
@@ -23,7 +23,7 @@ int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src,
                 HIPCHK(launch_pp_gauss3(dev_src, H, W, (uint8_t*)ctx->pp_a.p, 0, 256, 0, (unsigned long long*)ctx->pp_tab.p, ctx->stream));
                 unsigned long long sm = 0;
                 HIPCHK(hipMemcpyAsync(&sm, ctx->pp_tab.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(hipStreamSynchronize(ctx->stream));
+                slot_sync(ctx, ctx->stream);
                 pil_blend_lut((int)((double)sm / (double)n + 0.5), (float)param, lut);
             } else {
                 pil_blend_lut(0, (float)param, lut);
@@ -31,23 +31,23 @@ int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src,
             ctx->pp_tab.ensure(512);
             HIPCHK(hipMemcpyAsync((unsigned char*)ctx->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(launch_pp_lut(dev_src, dev_dst, (const uint8_t*)ctx->pp_tab.p + 256, n, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            slot_sync(ctx, ctx->stream);
         } else if (stage == 4) {
             pp_clahe(ctx, dev_src, H, W, nullptr, dev_dst, param);
         } else if (stage == 5) {
             ctx->pp_b.ensure(n);
             ctx->pp_c.ensure(n);
             pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, (float)param, 30, 3);
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            slot_sync(ctx, ctx->stream);
         } else if (stage == 7) {
             ctx->pp_b.ensure(n);
             ctx->pp_c.ensure(n);
             pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, 1.0f, (int)param, 3);
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            slot_sync(ctx, ctx->stream);
         } else if (stage == 6) {
             // cv2.cvtColor(BGR2GRAY) on an interleaved 3-channel plane [H,W,3] (the gray plane reformat_input derives from arrays)
             HIPCHK(launch_gray(dev_src, dev_dst, n, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            slot_sync(ctx, ctx->stream);
         } else {
             fail(BBOCR_ERR_ARG, "unknown pre-processing stage");
         }
@@ -117,7 +117,7 @@ int bbocr_host_ctc_beam(const float* probs, int n, int T, int C, int cs, int bea
 int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, int KH,
                     int KW, int pad, int dil, int relu_in, int relu_out, int out_f32, void* dev_out, int pool_mode, int pool_relu,
                     uint16_t* dev_pool_out) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_in || !w || Cin <= 0 || (Cin & 31) || Cout <= 0 || KH <= 0 || KW <= 0) fail(BBOCR_ERR_ARG, "bad conv arguments");
         if (pool_mode < 0 || pool_mode > 2 || (pool_mode ? (!dev_pool_out || out_f32) : !dev_out)) fail(BBOCR_ERR_ARG, "bad conv output arguments");
         ConvPlan p = make_plan(Cin, Cout, KH, KW, pad, dil, det_el(ctx));     // element type of the context's precision (bf16 / fp16)
@@ -138,11 +138,11 @@ int bbocr_op_conv2d(bbocr_ctx* ctx, const uint16_t* dev_in, int N, int H, int W,
         while (ctx->owned.size() > owned0) { (void)hipFree(ctx->owned.back()); ctx->owned.pop_back(); ctx->owned_bytes.pop_back(); }
         HIPCHK(e);
         HIPCHK(e2);
-    });
+    }, /*exclusive=*/true);      // uploads a temporary plan into the root's weight list
 }
 
 int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW, float* dev_logits) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!ctx->crnn_loaded) fail(BBOCR_ERR_STATE, "recogniser weights not loaded");
         if (!dev_crops || !dev_logits || n <= 0 || imgW < 64 || (imgW & 63)) fail(BBOCR_ERR_ARG, "bad crop batch");
         const int T = imgW / 4 - 1;
@@ -163,13 +163,13 @@ int bbocr_crnn_logits(bbocr_ctx* ctx, const uint16_t* dev_crops, int n, int imgW
         HIPCHK(hipMemcpyAsync(ctx->seq_tables.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         crnn_sequence(ctx, rows_pad, (const int*)ctx->seq_tables.p, (int)(tiles.size() / 4), (float*)ctx->seq_logits.p);
         HIPCHK(hipMemcpyAsync(dev_logits, ctx->seq_logits.p, rows * 112 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot_sync(ctx, ctx->stream);
     });
 }
 
 int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, int cs, int* text_off, int* text_idx, double* conf,
                  const unsigned int* ignore_mask, int beam_width) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_logits || !text_off || !text_idx || !conf || n <= 0 || T <= 0 || C <= 0 || C > cs) fail(BBOCR_ERR_ARG, "bad ctc arguments");
         const bool beam = beam_width > 0;
         const size_t rows = (size_t)n * T;
@@ -191,7 +191,7 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
         HIPCHK(hipMemcpyAsync(oidx.data(), ctx->ctc_out_idx.p, oidx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(oo.data(), ctx->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, ctx->stream));
         if (beam) HIPCHK(hipMemcpyAsync(probs.data(), ctx->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot_sync(ctx, ctx->stream);
         if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), n, C, cs, beam_width, beam_texts);
         int o = 0;
         for (int i = 0; i < n; ++i) {
@@ -205,16 +205,16 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
 }
 
 int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_src || !dev_dst || N <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0) fail(BBOCR_ERR_ARG, "bad resize arguments");
         HIPCHK(launch_resize_u8(dev_src, N, sh, sw, C, dev_dst, dh, dw, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot_sync(ctx, ctx->stream);
     });
 }
 
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free, int imgW,
                    float contrast, uint16_t* dev_out, int* n_out, int mode) {
-    return guarded(ctx, [&] {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
         if (!dev_gray || !dev_out || !n_out || imgW < 64 || (imgW & 63) || mode < 0 || mode > 4) fail(BBOCR_ERR_ARG, "bad crop arguments");
         std::vector<BoxJob> jobs;
         auto take = [&](BoxJob& j) {
@@ -271,7 +271,7 @@ int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const 
                                     (unsigned int*)ctx->crop_hist.p, ctx->stream));
             std::vector<unsigned int> hist(descs.size() * 256);
             HIPCHK(hipMemcpyAsync(hist.data(), ctx->crop_hist.p, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            slot_sync(ctx, ctx->stream);
             std::vector<uint8_t> luts(descs.size() * 256);
             for (size_t k = 0; k < descs.size(); ++k) {
                 const size_t npx = (size_t)descs[k].rw * descs[k].rh;
@@ -294,7 +294,7 @@ int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const 
         HIPCHK(launch_crops(dev_gray, H, W, (const CropDesc*)ctx->crop_desc.p, 0, (int)descs.size(), imgW, any_warp, any_tall,
                             (uint8_t*)ctx->crop_wscratch.p, (uint8_t*)ctx->crop_scratch.p, (uint8_t*)ctx->crop_hscratch.p,
                             (const uint8_t*)ctx->crop_luts.p, dev_out, 2, ctx->stream, 0, 0, rec_mode(ctx)));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot_sync(ctx, ctx->stream);
     });
 }
 

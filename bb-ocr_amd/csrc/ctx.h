@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -109,34 +110,15 @@ struct Act {   // bf16 NHWC activation
 
 
 
-struct bbocr_ctx {
-    bbocr_config cfg{};
-    hipStream_t stream = nullptr;
-    DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
-    unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
-    int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
-    hipStream_t cur = nullptr;                // stream the layer helpers launch on
-    hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream`
-    std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
-    hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
-    hipEvent_t det_t0 = nullptr, det_t1 = nullptr;   // detector span on `stream` (the host is busy with boxes meanwhile)
-    std::mutex mu;
-    std::string err;
-    float times[8] = {0};
-
-    // ---- optional per-launch timing of the conv_mfma kernel (HIP events on this context's stream)
-    struct ProfRec { hipEvent_t e0, e1; double flops; int group; };
-    int profiling = 0;                        // 0 off, 1 = time the detector's conv launches (group 0), 2 = also the recogniser's
-    int prof_group = 0;                     // 0 = detector, 1 = recogniser
-    std::vector<ProfRec> prof_recs;
-    std::vector<hipEvent_t> prof_pool;
-    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
-    long long prof_launches[2] = {0, 0};
-
+// Everything bbocr_load_weights leaves on the device, as the kernels read it.  A context's extra CALL SLOTS (below) hold a copy of this
+// view -- pointers into the root context's blocks, which alone owns (and frees) them.
+struct WeightView {
     // ---- detector
     bool craft_loaded = false;
     uint16_t* c11_wf = nullptr;               // conv1_1 weights in the layout of the producer fused into conv1_2
     float* c11_b = nullptr;
+    float* c11_w32 = nullptr;                 // exact mode: conv1_1 folded fp32 [64][3][3][3] (craft_pair.hip::pair_conv1_1_kernel)
+    float* cls6_w32 = nullptr;                // exact mode: conv_cls.6.weight fp32 [16][16] (pair_cls_tail_kernel)
     ConvPlan conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3, conv4_1, conv4_2, conv4_3, conv5_1, conv5_2, fc6, fc7;
     ConvPlan up1a, up1b, up2b, up3b, up4b, cls0, cls2, cls4;
     // U-net 1x1 layers over cat[up(y), skip], split by linearity: upNy = the columns of y (no bias, run at y's resolution),
@@ -152,10 +134,51 @@ struct bbocr_ctx {
     ConvPlan r1, r2, r3, r4, r5, r6, xproj[2], lin[2], pred;
     uint16_t* whh[2] = {nullptr, nullptr};
     float whh_scale[2] = {1.f, 1.f};   // exact mode: 2^-s of the packed W_hh (pack_lstm_whh_split)
-    std::vector<void*> owned;    // every hipMalloc'd weight block, in load order (the order of the weight blob, bbocr_weights_export)
+    void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
+};
+
+// One bbocr_ctx = the ROOT (what bbocr_create returns: configuration, weights, the compute stream, the call-slot pool) and, at the
+// same time, call slot 0.  The reference shares ONE Reader between ThreadPoolExecutor workers (batch_processor_enhanced.py:215,
+// default 2): a second call arriving while one is in flight takes a second slot -- a context of the same type that owns its own work
+// buffers, side stream and events, shares the root's weights (WeightView copy) and queues its kernels on the SAME compute stream, so
+// the card executes the two calls' kernels in issue order with no gap: call B's detector runs while call A's host thread is busy
+// with the last pass's box geometry, CTC read-back and result export (the ~8 % of a step that left the card idle).
+struct bbocr_ctx : WeightView {
+    bbocr_config cfg{};
+    bbocr_ctx* root = nullptr;                // slot -> its root; the root points at itself
+    std::vector<bbocr_ctx*> slots;            // root only: extra call slots, created when a second call arrives while the first is running
+    std::mutex pool_mu;                       // root only: guards slot_busy / slots / err / prof totals / last_times
+    std::condition_variable pool_cv;
+    std::mutex enq_mu;                        // root only: held while a slot queues ONE block of launches (a detector pass, a recogniser part, a
+                                              // sequence stage) on the shared compute stream, so that blocks of concurrent calls do not interleave kernel
+                                              // by kernel (the per-launch HIP events of the roofline leg would then time foreign kernels too)
+    bool slot_busy = false;                   // this slot is running a call
+    hipStream_t stream = nullptr;             // the compute stream (root's; slots share it: kernels of concurrent calls run in issue order)
+    DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
+    unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
+    int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
+    hipStream_t cur = nullptr;                // stream the layer helpers launch on
+    hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream` (per slot)
+    std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
+    hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
+    hipEvent_t det_t0 = nullptr, det_t1 = nullptr;   // detector span on `stream` (the host is busy with boxes meanwhile)
+    hipEvent_t sync_ev = nullptr;             // "this slot's work so far" on a stream (slot_sync)
+    hipEvent_t seq_t1 = nullptr, seq_t2 = nullptr;   // end of the sequence stage / of CTC + read-back (rec_finish)
+    std::string err;                          // root: message of the last failed call (any slot)
+    float times[8] = {0};                     // the running call's stage times; published per calling thread when the call ends
+
+    // ---- optional per-launch timing of the conv_mfma kernel (HIP events on the compute stream)
+    struct ProfRec { hipEvent_t e0, e1; double flops; int group; };
+    int profiling = 0;                        // root: 0 off, 1 = time the detector's conv launches (group 0), 2 = also the recogniser's
+    int prof_group = 0;                     // 0 = detector, 1 = recogniser
+    std::vector<ProfRec> prof_recs;           // per slot: launches recorded by the running call
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};   // root: totals
+    long long prof_launches[2] = {0, 0};
+
+    std::vector<void*> owned;    // root: every hipMalloc'd weight block, in load order (the order of the weight blob, bbocr_weights_export)
     std::vector<size_t> owned_bytes;
 
-    void* zero_page = nullptr;   // 256 zero bytes (padding source of the LDS-DMA conv variant)
     Arena arena;
     DevBuf heat, gray, resized;
     DevBuf ccl_label, ccl_stat, ccl_slot, ccl_comps, ccl_rowext, ccl_counters;
@@ -170,6 +193,7 @@ struct bbocr_ctx {
 inline int det_el(const bbocr_ctx* c) { return (c->cfg.precision == BBOCR_PREC_FP16 || c->cfg.precision == BBOCR_PREC_EXACT) ? 1 : 0; }
 inline int rec_el(const bbocr_ctx* c) { return c->cfg.precision != BBOCR_PREC_BF16 ? 1 : 0; }     // MIXED: bf16 detector, fp16 recogniser
 inline bool rec_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT; }   // recogniser tensors are [hi | lo] fp16 pairs
+inline bool det_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT; }   // and so are the detector's (split-fp16 plans in every layer)
 
 // ------------------------------------------------------------------------------------------------ shared types
 struct TensorMap {
@@ -299,6 +323,24 @@ void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent, int threshold);
 void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const bbocr_preproc_params& q, uint8_t* out, int dh, int dw);
 
+// ---- call slots
+struct EnqLock {       // see bbocr_ctx::enq_mu; never held across a host wait for the device
+    std::unique_lock<std::mutex> lk;
+    explicit EnqLock(bbocr_ctx* c) : lk(c->root->enq_mu) {}
+};
+constexpr int kMaxSlots = 2;       // calls in flight per context (the reference runs 2 ThreadPoolExecutor workers on one Reader)
+bbocr_ctx* slot_create(bbocr_ctx* root);                 // abi.cpp
+void slot_destroy(bbocr_ctx* s);                         // abi.cpp (everything but the shared compute stream and the weights)
+void publish_times(const bbocr_ctx* s);                  // abi.cpp: the finished call's stage times -> the calling thread's record
+
+// wait for what THIS slot has queued on `st` so far (the compute stream is shared between slots: hipStreamSynchronize would also wait for
+// the other call's kernels queued behind ours -- and the card would then run dry while both hosts wait)
+inline void slot_sync(bbocr_ctx* c, hipStream_t st) {
+    if (!c->sync_ev) HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->sync_ev, st));
+    HIPCHK(hipEventSynchronize(c->sync_ev));
+}
+
 // bbocr.h promises that a call returns with its own work finished -- also when it fails half-way: kernels already queued may still
 // read caller-owned inputs / write caller-owned outputs, and host vectors that were async-copy targets die during unwinding
 inline void guarded_drain(bbocr_ctx* ctx) {
@@ -309,31 +351,91 @@ inline void guarded_drain(bbocr_ctx* ctx) {
     ctx->prof_recs.clear();
 }
 
-// every ABI entry point runs inside guarded(): device selected, context locked, exceptions mapped to status codes
-template <typename F> inline int guarded(bbocr_ctx* ctx, F&& f) {
-    if (!ctx) return BBOCR_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// RAII lease of a call slot.  exclusive: every slot (weight loading / export / import, anything that changes what the slots share).
+struct SlotLease {
+    bbocr_ctx* root;
+    bbocr_ctx* slot = nullptr;
+    bool exclusive;
+    SlotLease(bbocr_ctx* r, bool excl) : root(r), exclusive(excl) {
+        std::unique_lock<std::mutex> lk(root->pool_mu);
+        const int max_slots = root->cfg.call_slots == 1 ? 1 : kMaxSlots;
+        if (exclusive) {
+            root->pool_cv.wait(lk, [&] {
+                if (root->slot_busy) return false;
+                for (bbocr_ctx* s : root->slots) if (s->slot_busy) return false;
+                return true;
+            });
+            root->slot_busy = true;
+            for (bbocr_ctx* s : root->slots) s->slot_busy = true;
+            slot = root;
+            return;
+        }
+        for (;;) {
+            if (!root->slot_busy) { slot = root; break; }
+            for (bbocr_ctx* s : root->slots) if (!s->slot_busy) { slot = s; break; }
+            if (slot) break;
+            if ((int)root->slots.size() + 1 < max_slots) {
+                slot = slot_create(root);              // may throw StatusError: nothing is leased then
+                root->slots.push_back(slot);
+                break;
+            }
+            root->pool_cv.wait(lk);
+        }
+        slot->slot_busy = true;
+        if (slot != root) {
+            static_cast<WeightView&>(*slot) = static_cast<const WeightView&>(*root);   // weights may have been loaded since the slot was made
+            slot->cfg = root->cfg;
+            slot->profiling = root->profiling;
+        }
+    }
+    ~SlotLease() {
+        {
+            std::lock_guard<std::mutex> lk(root->pool_mu);
+            if (exclusive) {
+                root->slot_busy = false;
+                for (bbocr_ctx* s : root->slots) s->slot_busy = false;
+            } else if (slot) {
+                slot->slot_busy = false;
+            }
+        }
+        root->pool_cv.notify_all();
+    }
+};
+
+// every ABI entry point runs inside guarded(): device selected, a call slot leased, exceptions mapped to status codes.  f(slot) does the work.
+template <typename F> inline int guarded(bbocr_ctx* root, F&& f, bool exclusive = false) {
+    if (!root) return BBOCR_ERR_ARG;
+    auto set_err = [&](const std::string& m) {
+        std::lock_guard<std::mutex> lk(root->pool_mu);
+        root->err = m;
+    };
+    bbocr_ctx* ctx = nullptr;
     try {
-        hipError_t e = hipSetDevice(ctx->cfg.device);
+        hipError_t e = hipSetDevice(root->cfg.device);
         if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-        ctx->cur = ctx->stream;
-        // the library runs on its own non-blocking streams: what the caller queued on the default stream (torch's) -- fills of
-        // output buffers, input copies -- must be complete before our kernels touch the same memory
-        e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("default stream: ") + hipGetErrorString(e));
-        f();
-        return BBOCR_OK;
+        SlotLease lease(root, exclusive);
+        ctx = lease.slot;
+        try {
+            ctx->cur = ctx->stream;
+            // the library runs on its own non-blocking streams: what the caller queued on the default stream (torch's) -- fills of
+            // output buffers, input copies -- must be complete before our kernels touch the same memory
+            e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) fail(BBOCR_ERR_HIP, std::string("default stream: ") + hipGetErrorString(e));
+            f(ctx);
+            publish_times(ctx);
+            return BBOCR_OK;
+        } catch (...) {
+            guarded_drain(ctx);                      // still inside the lease: nobody else touches this slot's buffers meanwhile
+            throw;
+        }
     } catch (const StatusError& se) {
-        ctx->err = se.msg;
-        guarded_drain(ctx);
+        set_err(se.msg);
         return se.code;
     } catch (const std::exception& ex) {
-        ctx->err = ex.what();
-        guarded_drain(ctx);
+        set_err(ex.what());
         return BBOCR_ERR_INTERNAL;
     } catch (...) {
-        ctx->err = "unknown failure";
-        guarded_drain(ctx);
+        set_err("unknown failure");
         return BBOCR_ERR_INTERNAL;
     }
 }

@@ -86,12 +86,14 @@ void run_conv(bbocr_ctx* c, const ConvPlan& p, const Act& a0, bool relu0, const 
 
 // after the stream has drained: fold the recorded launches into the per-group totals
 void prof_collect(bbocr_ctx* c) {
+    bbocr_ctx* root = c->root;
+    std::lock_guard<std::mutex> lk(root->pool_mu);
     for (auto& r : c->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-            c->prof_ms[r.group] += ms;
-            c->prof_flops[r.group] += r.flops;
-            c->prof_launches[r.group] += 1;
+            root->prof_ms[r.group] += ms;
+            root->prof_flops[r.group] += r.flops;
+            root->prof_launches[r.group] += 1;
         }
         c->prof_pool.push_back(r.e0);
         c->prof_pool.push_back(r.e1);
@@ -228,6 +230,57 @@ static void craft_forward(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, in
     }
 }
 
+// EXACT mode: the same network on pair tensors [hi | lo] (22 significand bits) with split-fp16 plans in every layer, in the reference's own
+// operation order (easyocr/craft.py::CRAFT.forward): conv1_1 as its own fp32 launch, ReLU / pool5 / F.interpolate + torch.cat as
+// element-wise passes on the pair values (craft_pair.hip), the U-net 1x1s over the materialised concat, the classifier tail in fp32.
+// 3x the MFMA work of the fp16 pass plus the un-fused intermediates: the price of threshold decisions that follow the fp32 CPU path's
+// on ANY heat-map, not only on maps with margins.
+static void craft_forward_exact(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
+    Arena& ar = c->arena;
+    c->prof_group = 0;
+    auto pair = [&](int N, int H, int W, int C) { return Act{ar.alloc<uint16_t>((size_t)N * H * W * C * 2), N, H, W, C * 2}; };   // Act::C counts both halves
+    auto relu = [&](const Act& a) {
+        Act o = pair(a.N, a.H, a.W, a.C / 2);
+        if (!ar.dry) HIPCHK(launch_pair_relu(a.p, o.p, (size_t)a.N * a.H * a.W, a.C / 2, c->cur));
+        return o;
+    };
+    auto upcat = [&](const Act& y, const Act& skip) {
+        Act o = pair(skip.N, skip.H, skip.W, y.C / 2 + skip.C / 2);
+        if (!ar.dry) HIPCHK(launch_pair_upcat(y.p, y.H, y.W, y.C / 2, skip.p, skip.C / 2, o.p, skip.N, skip.H, skip.W, c->cur));
+        return o;
+    };
+    auto conv = [&](const ConvPlan& p, const Act& a, bool relu_out, int store) { return conv_act(c, p, a, false, nullptr, false, relu_out, store); };
+    Act x0 = pair(nb, H32, W32, 64);
+    if (!ar.dry) HIPCHK(launch_pair_conv1_1(rgb, nb, Himg, Wimg, H32, W32, c->c11_w32, c->c11_b, x0.p, c->cur));
+    Act p1 = conv_pool_act(c, c->conv1_2, x0, false, true, 64, 1, false, nullptr);
+    Act a3 = conv(c->conv2_1, p1, true, 128);
+    Act s1;
+    Act p2 = conv_pool_act(c, c->conv2_2, a3, false, false, 128, 1, true, &s1);     // slice1 ends on BN (s1); slice2 opens with ReLU + pool
+    Act a5 = conv(c->conv3_1, p2, true, 256);
+    Act s2 = conv(c->conv3_2, a5, false, 256);
+    Act p3 = conv_pool_act(c, c->conv3_3, relu(s2), false, true, 256, 1, false, nullptr);
+    Act a8 = conv(c->conv4_1, p3, true, 512);
+    Act s3 = conv(c->conv4_2, a8, false, 512);
+    Act p4 = conv_pool_act(c, c->conv4_3, relu(s3), false, true, 512, 1, false, nullptr);
+    Act a11 = conv(c->conv5_1, p4, true, 512);
+    Act s4 = conv(c->conv5_2, a11, false, 512);
+    Act p5 = pair(s4.N, s4.H, s4.W, 512);
+    if (!ar.dry) HIPCHK(launch_pair_maxpool3x3s1(s4.p, p5.p, s4.N, s4.H, s4.W, 512, c->cur));
+    Act f6 = conv(c->fc6, p5, false, 1024);
+    Act f7 = conv(c->fc7, f6, false, 1024);
+    Act u1b = conv(c->up1b, conv(c->up1a, upcat(f7, s4), true, 512), true, 256);
+    Act u2b = conv(c->up2b, conv(c->up2s, upcat(u1b, s3), true, 256), true, 128);
+    Act u3b = conv(c->up3b, conv(c->up3s, upcat(u2b, s2), true, 128), true, 64);
+    Act u4b = conv(c->up4b, conv(c->up4s, upcat(u3b, s1), true, 64), true, 32);
+    Act c3 = conv(c->cls4, conv(c->cls2, conv(c->cls0, u4b, true, 32), true, 32), true, 16);
+    if (!ar.dry) HIPCHK(launch_pair_cls_tail(c3.p, c->cls6_w32, c->cls_tail, heat, (size_t)c3.N * c3.H * c3.W, c->cur));
+}
+
+static void craft_forward_any(bbocr_ctx* c, const uint8_t* rgb, int nb, int Himg, int Wimg, int H32, int W32, float* heat) {
+    if (det_split(c)) craft_forward_exact(c, rgb, nb, Himg, Wimg, H32, W32, heat);
+    else craft_forward(c, rgb, nb, Himg, Wimg, H32, W32, heat);
+}
+
 DetDims det_dims(int H, int W, int canvas, double mag) {
     DetDims d;
     double target = mag * (double)std::max(H, W);
@@ -257,7 +310,7 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
         for (int b0 = 0; b0 < B; b0 += c->cfg.det_sub_batch) passes.push_back(std::min(c->cfg.det_sub_batch, B - b0));
     } else {
         c->arena.begin(true);
-        craft_forward(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
+        craft_forward_any(c, nullptr, 1, d.th, d.tw, d.H32, d.W32, nullptr);
         const size_t per_page = std::max<size_t>(c->arena.off, 1);
         const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)96 << 30) / per_page));
         static const int tail_knob = diag_knob("BBOCR_DET_TAIL", 8);   // A/B knob: tail length in 1280x960-page equivalents
@@ -273,17 +326,18 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
     const bool need_resize = (d.th != H || d.tw != W);
     if (need_resize) c->resized.ensure((size_t)sb * d.th * d.tw * 3);
     c->arena.begin(true);
-    craft_forward(c, nullptr, sb, d.th, d.tw, d.H32, d.W32, nullptr);
+    craft_forward_any(c, nullptr, sb, d.th, d.tw, d.H32, d.W32, nullptr);
     c->arena.buf.ensure(c->arena.off);
     int b0 = 0;
     for (const int nb : passes) {
+        EnqLock enq(c);                       // one detector pass = one contiguous block on the compute stream
         const uint8_t* src = rgb + (size_t)b0 * H * W * 3;
         if (need_resize) {
             HIPCHK(launch_resize_u8(src, nb, H, W, 3, (uint8_t*)c->resized.p, d.th, d.tw, c->stream));
             src = (const uint8_t*)c->resized.p;
         }
         c->arena.begin(false);
-        craft_forward(c, src, nb, d.th, d.tw, d.H32, d.W32, heat + (size_t)b0 * d.h * d.w * 2);
+        craft_forward_any(c, src, nb, d.th, d.tw, d.H32, d.W32, heat + (size_t)b0 * d.h * d.w * 2);
         if (after_sub) after_sub(b0, nb);   // everything of this sub-batch is enqueued (nothing has been waited for)
         b0 += nb;
     }
@@ -313,13 +367,13 @@ void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double rat
     HIPCHK(hipEventRecord(c->ccl_t1, st));
     int counters[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(counters, c->ccl_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    slot_sync(c, st);
     if (counters[2]) fail(BBOCR_ERR_OVERFLOW, "component buffers too small for this batch");
     std::vector<CclOut> all_comps(counters[0]);
     std::vector<int> all_rows((size_t)counters[1] * 2);
     if (counters[0]) HIPCHK(hipMemcpyAsync(all_comps.data(), c->ccl_comps.p, all_comps.size() * sizeof(CclOut), hipMemcpyDeviceToHost, st));
     if (counters[1]) HIPCHK(hipMemcpyAsync(all_rows.data(), c->ccl_rowext.p, all_rows.size() * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    slot_sync(c, st);
     std::vector<std::vector<CclOut>> comps(B);
     for (const CclOut& co : all_comps)
         if (co.img >= 0 && co.img < B) comps[co.img].push_back(co);

@@ -85,6 +85,17 @@ hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
 hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw, hipStream_t s);
 
+// ------------------------------------------------------------------ exact detector, element-wise helpers on pair tensors (craft_pair.hip)
+// pair tensor = [hi C | lo C] fp16 per pixel, value = hi + lo / 2048 (REC_SPLIT below); C % 8 == 0 everywhere
+hipError_t launch_pair_conv1_1(const uint8_t* rgb, int N, int Hi, int Wi, int H, int W, const float* w /*[64][3][3][3] folded*/, const float* b, uint16_t* out,
+                               hipStream_t s);
+hipError_t launch_pair_relu(const uint16_t* in, uint16_t* out, size_t npix, int C, hipStream_t s);
+hipError_t launch_pair_maxpool3x3s1(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t s);
+// out = cat([interpolate(y -> H x W, bilinear, align_corners=False), skip]) (yh x yw == H x W: plain concat)
+hipError_t launch_pair_upcat(const uint16_t* y, int yh, int yw, int Cy, const uint16_t* skip, int Cs, uint16_t* out, int N, int H, int W, hipStream_t s);
+hipError_t launch_pair_cls_tail(const uint16_t* in /*[npix, 16 | 16]*/, const float* w1 /*[16][16]*/, const float* tail /*b1[16] w2[32] b2[2]*/, float* heat,
+                                size_t npix, hipStream_t s);
+
 // ------------------------------------------------------------------ box extraction (ccl.hip)
 struct CclOut {        // per accepted component, device-written, host-sorted by root
     int root, left, top, right, bottom, area, row_off, img;

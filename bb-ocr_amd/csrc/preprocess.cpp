@@ -77,7 +77,7 @@ void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int
     HIPCHK(hipMemcpyAsync(x0, ax.first.data(), nx * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(y0, ay.first.data(), ny * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, ax.K, ay.K, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // the host tables must outlive the copies
+    slot_sync(c, c->stream);   // the host tables must outlive the copies
 }
 // GaussianBlur 3x3; returns the sum of the output pixels (for the following Contrast step)
 unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma) {
@@ -88,7 +88,7 @@ unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint
     HIPCHK(launch_pp_gauss3(src, H, W, dst, k[0], k[1], k[2], (unsigned long long*)c->pp_tab.p, c->stream));
     unsigned long long sum = 0;
     HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
     return sum;
 }
 // CLAHE of lut[src] (lut = pointwise steps folded in front of it; identity if null)
@@ -111,7 +111,7 @@ void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut
     HIPCHK(launch_pp_clahe_hist(src, H, W, d_lut, tw, th, tx, ty, d_hist, c->stream));
     std::vector<unsigned int> hist((size_t)tx * ty * 256);
     HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
     // imgproc clahe.cpp: clip + redistribute, LUT = cvRound(cumsum * 255 / tile_area) in float
     const int area = th * tw;
     const float lut_scale = 255.0f / (float)area;
@@ -141,7 +141,7 @@ void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut
     }
     HIPCHK(hipMemcpyAsync(d_tl, tl.data(), tl.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(launch_pp_clahe_apply(src, H, W, d_lut, d_tl, tw, th, tx, ty, dst, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
 }
 // PIL UnsharpMask on src -> dst; tmp1/tmp2: two scratch planes of the same size
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent,
@@ -197,7 +197,7 @@ void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const
             uint8_t* d = next();
             HIPCHK(launch_pp_gauss3(cur, dh, dw, d, 0, 256, 0, (unsigned long long*)c->pp_tab.p, c->stream));
             HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            slot_sync(c, c->stream);
             cur = d;
         }
         uint8_t l1[256];
@@ -220,7 +220,7 @@ void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const
         c->pp_tab.ensure(512);
         HIPCHK(hipMemcpyAsync((unsigned char*)c->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, c->stream));
         HIPCHK(launch_pp_lut(cur, d, (const uint8_t*)c->pp_tab.p + 256, n, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        slot_sync(c, c->stream);
         cur = d;
     }
     if (q.unsharp_percent > 0 && q.unsharp_radius > 0) {
@@ -229,5 +229,5 @@ void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const
     } else {
         HIPCHK(hipMemcpyAsync(out, cur, n, hipMemcpyDeviceToDevice, c->stream));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
 }

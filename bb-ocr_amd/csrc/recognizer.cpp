@@ -174,6 +174,7 @@ static void rec_plan_part(const std::vector<BoxJob>& jobs, const std::vector<int
 // conv stack, pooled rows into seq_v.  Nothing here waits for the device (the buffers it needs are sized by the caller).
 static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, const RecPart& part, DevBuf& desc_buf, bool stage_a) {
     if (part.descs.empty()) return;
+    EnqLock enq(c);                           // one feature part = one contiguous block on the compute stream
     const size_t bytes = part.descs.size() * sizeof(CropDesc);
     desc_buf.ensure(bytes);
     PinBuf& pin = (&desc_buf == &c->crop_desc2) ? c->desc_pin2 : c->desc_pin;
@@ -235,30 +236,40 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
     c->seq_tables.ensure((tiles.size() + seqs.size()) * 4);
     int* tiles_dev = (int*)c->seq_tables.p;
     int* seqs_dev = tiles_dev + tiles.size();
-    HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
-    crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->times[4] += (float)ms_since(t0);
-    t0 = clk::now();
     c->ctc_idx.ensure(rows * 4);
     c->ctc_pmax.ensure(rows * 4);
     c->ctc_out_idx.ensure(rows * 4);
     c->ctc_out.ensure((size_t)nseq * sizeof(CtcOut));
     const bool beam = c->beam_width > 0;
     if (beam) c->ctc_probs.ensure(rows * 112 * sizeof(float));
-    HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
-                      (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
     const size_t oo_off = align_up(rows * 4, 16);
     c->ctc_pin.ensure(oo_off + (size_t)nseq * sizeof(CtcOut));
     const int* oidx = (const int*)c->ctc_pin.p;
     const CtcOut* oo = (const CtcOut*)((const char*)c->ctc_pin.p + oo_off);
     std::vector<float> probs(beam ? rows * 112 : 0);
     std::vector<std::vector<int>> beam_texts;
-    HIPCHK(hipMemcpyAsync(c->ctc_pin.p, c->ctc_out_idx.p, rows * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync((char*)c->ctc_pin.p + oo_off, c->ctc_out.p, (size_t)nseq * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
-    if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->seq_t1) { HIPCHK(hipEventCreate(&c->seq_t1)); HIPCHK(hipEventCreate(&c->seq_t2)); }
+    {
+        // sequence stage, CTC and the read-back of its results as ONE contiguous block on the compute stream and ONE host wait: with a
+        // second call in flight anything queued after a wait would land behind that call's whole detector
+        EnqLock enq(c);
+        HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
+        HIPCHK(hipEventRecord(c->seq_t1, c->stream));
+        HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
+                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
+        HIPCHK(hipMemcpyAsync(c->ctc_pin.p, c->ctc_out_idx.p, rows * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync((char*)c->ctc_pin.p + oo_off, c->ctc_out.p, (size_t)nseq * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
+        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->seq_t2, c->stream));
+    }
+    HIPCHK(hipEventSynchronize(c->seq_t2));
+    float ctc_ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ctc_ms, c->seq_t1, c->seq_t2));
+    c->times[4] += (float)ms_since(t0) - ctc_ms;     // host wait for the recogniser's device work (conv stack of the parts + sequence stage)
+    c->times[5] += ctc_ms;                           // CTC kernels + read-back (device span) ...
+    t0 = clk::now();                                 // ... + the host decode below
     if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
     for (int i = 0; i < nseq; ++i) {
         const int k = run.seq_k[i];
@@ -529,7 +540,7 @@ void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, cons
                             c->stream));
     std::vector<unsigned int> hist(ld.size() * 256);
     HIPCHK(hipMemcpyAsync(hist.data(), c->crop_hist.p, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
     // adjust_contrast_grey leaves a crop whose contrast is already >= the target untouched: its second prediction would be computed
     // from bit-identical input, equals the first one, and get_text's `pred1[1] > pred2[1] ? pred1 : pred2` picks the same pair either
     // way.  Only the crops that really change are run again.

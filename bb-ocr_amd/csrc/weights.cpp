@@ -50,7 +50,7 @@ void upload_plan(bbocr_ctx* c, ConvPlan& p, const std::vector<float>& w, const s
 // scaled by a power of two so that their largest magnitude sits in [512, 1024): w_lo = fp16(w 2^s - w_hi) then stays in fp16's
 // normal range for every weight that matters; the epilogue multiplies the accumulators by 2^-s (exact).
 static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int KH, int KW, int pad, const std::vector<float>& w,
-                              const std::vector<float>& b, float lo_scale = SPLIT_LO_SCALE) {    // lo_scale: what the producer multiplied its lo half by
+                              const std::vector<float>& b, float lo_scale = SPLIT_LO_SCALE, int dil = 1) {    // lo_scale: what the producer multiplied its lo half by
     if (Cin % 32) fail(BBOCR_ERR_INTERNAL, "split plan: Cin must be a multiple of 32");
     const int taps = KH * KW;
     float mx = 0.f;
@@ -71,7 +71,7 @@ static void upload_split_plan(bbocr_ctx* c, ConvPlan& p, int Cin, int Cout, int 
                 row[((size_t)Cin + i) * taps + t] = hi * (1.f / lo_scale);            // the lo activations are stored x lo_scale (2048; 1 behind the LSTM)
                 row[((size_t)2 * Cin + i) * taps + t] = lo;
             }
-    p = make_plan(3 * Cin, Cout, KH, KW, pad, 1, 1);
+    p = make_plan(3 * Cin, Cout, KH, KW, pad, dil, 1);
     p.acc_scale = std::ldexp(1.f, -s);
     p.split = 1;
     upload_plan(c, p, w3, b);
@@ -99,7 +99,7 @@ static void load_layer(bbocr_ctx* c, const TensorMap& tm, ConvPlan& p, const std
     std::vector<float> w, b;
     fold_conv(tm, conv, bn, Cout, Cin, K * K, w, b);
     if (split) {
-        upload_split_plan(c, p, Cin, Cout, K, K, pad, w, b);
+        upload_split_plan(c, p, Cin, Cout, K, K, pad, w, b, SPLIT_LO_SCALE, dil);
         return;
     }
     p = make_plan(Cin, Cout, K, K, pad, dil, el, tile_bn);
@@ -134,6 +134,9 @@ std::vector<float*> blob_scalars(bbocr_ctx* c) {       // host scalars that depe
     for (ConvPlan* p : {&c->r1, &c->r2, &c->r3, &c->r4, &c->r5, &c->r6, &c->xproj[0], &c->xproj[1], &c->lin[0], &c->lin[1], &c->pred}) v.push_back(&p->acc_scale);
     v.push_back(&c->whh_scale[0]);
     v.push_back(&c->whh_scale[1]);
+    for (ConvPlan* p : {&c->conv1_2, &c->conv2_1, &c->conv2_2, &c->conv3_1, &c->conv3_2, &c->conv3_3, &c->conv4_1, &c->conv4_2, &c->conv4_3, &c->conv5_1,
+                        &c->conv5_2, &c->fc6, &c->fc7, &c->up1a, &c->up1b, &c->up2s, &c->up2b, &c->up3s, &c->up3b, &c->up4s, &c->up4b, &c->cls0, &c->cls2, &c->cls4})
+        v.push_back(&p->acc_scale);       // exact mode: the detector's split plans (1 otherwise)
     return v;
 }
 }  // namespace
@@ -141,7 +144,7 @@ std::vector<float*> blob_scalars(bbocr_ctx* c) {       // host scalars that depe
 size_t weights_blob_bytes(const bbocr_ctx* c) {
     size_t n = sizeof(BlobHeader);
     for (size_t b : c->owned_bytes) n += align_up(b, 256);
-    return n + 256;                                     // trailer: <= 64 floats
+    return n + 256;                                     // trailer: 64 floats (blob_scalars: 37 used)
 }
 
 void weights_export(bbocr_ctx* c, void* dev_dst, size_t bytes) {
@@ -161,7 +164,7 @@ void weights_export(bbocr_ctx* c, void* dev_dst, size_t bytes) {
     const std::vector<float*> sc = blob_scalars(c);
     for (size_t i = 0; i < sc.size(); ++i) tr[i] = *sc[i];
     HIPCHK(hipMemcpyAsync(d + off, tr, sizeof(tr), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
 }
 
 void weights_import(bbocr_ctx* c, const void* dev_src, size_t bytes) {
@@ -179,12 +182,65 @@ void weights_import(bbocr_ctx* c, const void* dev_src, size_t bytes) {
     }
     float tr[64];
     HIPCHK(hipMemcpyAsync(tr, s + off, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    slot_sync(c, c->stream);
     const std::vector<float*> sc = blob_scalars(c);
     for (size_t i = 0; i < sc.size(); ++i) *sc[i] = tr[i];
 }
 
+// EXACT mode: every detector layer as a split-fp16 plan over pair tensors; the layers the fast modes fuse or commute (conv1_1 inside
+// conv1_2, the U-net 1x1s split by linearity, upconv4 in one launch, the classifier tail in conv_cls.4's epilogue) run in the reference's
+// own operation order instead (detector.cpp::craft_forward_exact).
+static void load_craft_exact(bbocr_ctx* c, const TensorMap& tm) {
+    {
+        std::vector<float> w, b;
+        fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);
+        c->c11_w32 = upload(c, w);
+        c->c11_b = upload(c, b);
+    }
+    auto L = [&](ConvPlan& p, const char* conv, const char* bn, int Cin, int Cout, int K, int pad, int dil) {
+        load_layer(c, tm, p, conv, bn, Cin, Cout, K, pad, dil, 1, true);
+    };
+    L(c->conv1_2, "basenet.slice1.3", "basenet.slice1.4", 64, 64, 3, 1, 1);
+    L(c->conv2_1, "basenet.slice1.7", "basenet.slice1.8", 64, 128, 3, 1, 1);
+    L(c->conv2_2, "basenet.slice1.10", "basenet.slice1.11", 128, 128, 3, 1, 1);
+    L(c->conv3_1, "basenet.slice2.14", "basenet.slice2.15", 128, 256, 3, 1, 1);
+    L(c->conv3_2, "basenet.slice2.17", "basenet.slice2.18", 256, 256, 3, 1, 1);
+    L(c->conv3_3, "basenet.slice3.20", "basenet.slice3.21", 256, 256, 3, 1, 1);
+    L(c->conv4_1, "basenet.slice3.24", "basenet.slice3.25", 256, 512, 3, 1, 1);
+    L(c->conv4_2, "basenet.slice3.27", "basenet.slice3.28", 512, 512, 3, 1, 1);
+    L(c->conv4_3, "basenet.slice4.30", "basenet.slice4.31", 512, 512, 3, 1, 1);
+    L(c->conv5_1, "basenet.slice4.34", "basenet.slice4.35", 512, 512, 3, 1, 1);
+    L(c->conv5_2, "basenet.slice4.37", "basenet.slice4.38", 512, 512, 3, 1, 1);
+    L(c->fc6, "basenet.slice5.1", "", 512, 1024, 3, 6, 6);
+    L(c->fc7, "basenet.slice5.2", "", 1024, 1024, 1, 0, 1);
+    L(c->up1a, "upconv1.conv.0", "upconv1.conv.1", 1536, 512, 1, 0, 1);
+    L(c->up1b, "upconv1.conv.3", "upconv1.conv.4", 512, 256, 3, 1, 1);
+    L(c->up2s, "upconv2.conv.0", "upconv2.conv.1", 768, 256, 1, 0, 1);        // over cat[up(y), skip], channels in torch.cat's order
+    L(c->up2b, "upconv2.conv.3", "upconv2.conv.4", 256, 128, 3, 1, 1);
+    L(c->up3s, "upconv3.conv.0", "upconv3.conv.1", 384, 128, 1, 0, 1);
+    L(c->up3b, "upconv3.conv.3", "upconv3.conv.4", 128, 64, 3, 1, 1);
+    L(c->up4s, "upconv4.conv.0", "upconv4.conv.1", 192, 64, 1, 0, 1);
+    L(c->up4b, "upconv4.conv.3", "upconv4.conv.4", 64, 32, 3, 1, 1);
+    L(c->cls0, "conv_cls.0", "", 32, 32, 3, 1, 1);
+    L(c->cls2, "conv_cls.2", "", 32, 32, 3, 1, 1);
+    L(c->cls4, "conv_cls.4", "", 32, 16, 3, 1, 1);
+    {
+        const float* w1 = tm.get("conv_cls.6.weight", 256);
+        const float* b1 = tm.get("conv_cls.6.bias", 16);
+        const float* w2 = tm.get("conv_cls.8.weight", 32);
+        const float* b2 = tm.get("conv_cls.8.bias", 2);
+        std::vector<float> t(50);
+        std::copy(b1, b1 + 16, t.begin());
+        std::copy(w2, w2 + 32, t.begin() + 16);
+        std::copy(b2, b2 + 2, t.begin() + 48);
+        c->cls_tail = upload(c, t);
+        c->cls6_w32 = upload(c, std::vector<float>(w1, w1 + 256));
+    }
+    c->craft_loaded = true;
+}
+
 void load_craft(bbocr_ctx* c, const TensorMap& tm) {
+    if (det_split(c)) { load_craft_exact(c, tm); return; }
     {
         std::vector<float> w, b;
         fold_conv(tm, "basenet.slice1.0", "basenet.slice1.1", 64, 3, 9, w, b);

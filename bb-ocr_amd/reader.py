@@ -208,7 +208,7 @@ class Reader:
     def __init__(self, lang_list, gpu=True, model_storage_directory=None, user_network_directory=None,
                  detect_network="craft", recog_network="standard", download_enabled=True, detector=True, recognizer=True,
                  verbose=True, quantize=True, cudnn_benchmark=False, weights=None, device_index=None, det_sub_batch=0,
-                 rec_max_cols=0, precision=None, **_ignored):
+                 rec_max_cols=0, precision=None, call_slots=0, **_ignored):
         import torch
 
         if list(lang_list) != ["en"]:
@@ -221,7 +221,6 @@ class Reader:
         self.device_index = torch.cuda.current_device() if device_index is None else int(device_index)
         self.device = f"cuda:{self.device_index}"
         self._lib = _lib.load()
-        self._lock = threading.Lock()
         if precision is None:       # the reference constructs Reader(["en"], gpu=...) (enhanced_extractor.py:153): the mode comes from the environment
             # default "fp16": the cheapest mode whose boxes AND strings equalled the fp32 CPU path's on everything measured -- 2,051 boxes
             # of synthetic pages, 471 of dense A4 scans, 110 on the reference's seven real images.  "mixed" (bf16
@@ -231,7 +230,7 @@ class Reader:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
         self.precision = precision
         cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols),
-                                precision=_lib.PRECISIONS[precision])
+                                precision=_lib.PRECISIONS[precision], call_slots=int(call_slots))
         h = C.c_void_p()
         rc = self._lib.bbocr_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -411,6 +410,28 @@ class Reader:
             return [[item[1] for item in page] for page in pages] if kw.get("detail", 1) == 0 else pages
         return self._collect(res, kw.get("detail", 1))
 
+    def readtext_stream(self, batches, in_flight=2, **kw):
+        """Device page batches in, per-batch results out, IN ORDER, with up to ``in_flight`` calls running on this Reader at once.
+
+        The reference shares one Reader between ``ThreadPoolExecutor`` workers (batch_processor_enhanced.py:215, default 2); libbbocr gives
+        each concurrent call its own call slot (``bbocr_config::call_slots``), so batch k+1's detector is on the card while batch k's host
+        thread finishes box geometry, CTC read-back and result marshalling.  ``batches`` yields uint8 ``[B,H,W,3]`` device tensors or
+        ``(rgb, gray)`` pairs (it may produce them lazily, e.g. H2D copies: it is drained one batch ahead of the workers).  Results are those
+        of calling ``readtext_device`` batch by batch."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        in_flight = max(1, int(in_flight))
+        with ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="bbocr-call") as ex:
+            pending = deque()
+            for b in batches:
+                rgb, gray = b if isinstance(b, tuple) else (b, None)
+                pending.append(ex.submit(self.readtext_device, rgb, gray, **kw))
+                if len(pending) > in_flight:                 # one batch queued behind the running ones: a worker never waits for the producer
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+
     def readtext(self, image, decoder="greedy", beamWidth=5, batch_size=1, workers=0, allowlist=None, blocklist=None, detail=1,
                  rotation_info=None, paragraph=False, min_size=20, contrast_ths=0.1, adjust_contrast=0.5, filter_ths=0.003,
                  text_threshold=0.7, low_text=0.4, link_threshold=0.4, canvas_size=2560, mag_ratio=1.0, slope_ths=0.1, ycenter_ths=0.5,
@@ -444,11 +465,13 @@ class Reader:
         by_shape = {}
         for i, (a, g) in enumerate(pages):
             by_shape.setdefault(a.shape, []).append(i)
+        max_pages = int(os.environ.get("BBOCR_MAX_DEVICE_BATCH", "64"))     # pages per device batch; larger groups stream, two batches in flight
         for _, idxs in by_shape.items():
-            rgb = self._to_dev(np.stack([pages[i][0] for i in idxs]))
-            gray = self._to_dev(np.stack([pages[i][1] for i in idxs]))
-            for i, r in zip(idxs, self.readtext_device(rgb, gray, **kw)):
-                out[i] = format_output(r, output_format, kw.get("paragraph", False), kw.get("detail", 1))
+            chunks = [idxs[k:k + max_pages] for k in range(0, len(idxs), max_pages)]
+            feed = ((self._to_dev(np.stack([pages[i][0] for i in ch])), self._to_dev(np.stack([pages[i][1] for i in ch]))) for ch in chunks)
+            for ch, res in zip(chunks, self.readtext_stream(feed, **kw)):
+                for i, r in zip(ch, res):
+                    out[i] = format_output(r, output_format, kw.get("paragraph", False), kw.get("detail", 1))
         return out
 
     def readtext_arrays(self, rgb, gray=None, **kw):

@@ -16,13 +16,17 @@ _WORDS = ("the quick brown fox jumps over lazy dog beyond frontier romance of ea
 
 
 def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_size: int = 24, word_gap: int = 16, line_pitch: int = 40,
-         margin: int = 48, colour: bool = False, vocab=None):
+         margin: int = 48, colour: bool = False, vocab=None, faint: float = 0.0):
     """-> (rgb uint8 [H,W,3], word boxes [(x0,y0,x1,y1,text)]).
 
     ``colour=True`` tints paper and ink (a per-page offset on the red and blue channels plus per-pixel chroma noise; the green
     channel -- the one the designed detector reads -- keeps the grey page's values), so that R != G != B everywhere and the
     gray plane (cv2 BGR2GRAY on the device) is a genuine three-channel mix.
-    ``vocab`` replaces the built-in word list (tests/golden/train_crnn.py mixes in random letter strings)."""
+    ``vocab`` replaces the built-in word list (tests/golden/train_crnn.py mixes in random letter strings).
+    ``faint`` (0..1): that share of the text LINES is printed in an ink whose luminance nearly equals the paper's -- the green channel
+    (what the designed detector reads) keeps its dark strokes, red and blue are set so that cv2's gray plane shows the line at a
+    contrast of a few grey levels under the page noise.  The recogniser's confidence on such lines falls below ``contrast_ths`` and
+    upstream's contrast retry (``adjust_contrast_grey``) becomes live: the low-confidence workload of bench.py / the GPU tests."""
     from PIL import Image, ImageDraw, ImageFont
 
     rng = np.random.default_rng(seed)
@@ -36,9 +40,12 @@ def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_
     words = []
     vocab = _WORDS if vocab is None else vocab
     y = margin
+    faint_rows = []
     for _ in range(lines):
         if y + line_pitch > height - margin // 2:
             break
+        if faint > 0 and rng.random() < faint:
+            faint_rows.append((max(0, y - 6), min(height, y + line_pitch - 6)))
         x = margin + int(rng.integers(0, 24))
         limit = width - margin - int(rng.integers(0, width // 3))
         while True:
@@ -57,6 +64,19 @@ def page(seed: int, width: int = 1280, height: int = 960, lines: int = 20, font_
     fg = 30.0 + rng.uniform(-10.0, 10.0, (height, width))
     g = np.where(m, fg, bg)
     g = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    if faint_rows:
+        # gray = (9798 R + 19235 G + 3735 B) >> 15: choose R = B = v so that ink (G ~ 30) and paper (G ~ 235) land `delta` grey levels apart
+        frng = np.random.default_rng(seed + 11_000_027)
+        rb = np.repeat(g[:, :, None], 2, axis=2).astype(np.float64)
+        for (r0, r1) in faint_rows:
+            delta = float(frng.uniform(4.0, 14.0))
+            # paper: R = B = 60 -> gray ~ 0.413 * 60 + 0.587 * 235 = 162.7; ink: gray target = paper - delta
+            v_ink = (162.7 - delta - 0.587 * g[r0:r1].astype(np.float64)) / 0.413
+            v = np.where(m[r0:r1], v_ink, 60.0 + frng.normal(0.0, 2.0, (r1 - r0, width)))
+            rb[r0:r1, :, 0] = v
+            rb[r0:r1, :, 1] = v
+        rb = np.clip(np.rint(rb), 0, 255).astype(np.uint8)
+        return np.ascontiguousarray(np.stack([rb[..., 0], g, rb[..., 1]], axis=2)), words
     if not colour:
         return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)), words
     crng = np.random.default_rng(seed + 7_000_003)          # own stream: the grey page of a seed does not change

@@ -9,12 +9,15 @@ synthetic 1280x960 pages per GPU, pages already resident in HBM.  Workload = BAS
 ("Full CRAFT+CRNN detect+recognize, batch=64 @1280x960, 1 MI355X"); with N GPUs every rank processes its own
 64-page shard (weak scaling, no data-path collective; weights are broadcast once from rank 0 over RCCL) -- at N = 8
 that is BASELINE.json configs[3] (512 pages sharded across 8 MI355X).  `--config a4` runs configs[4]'s per-GPU share
-instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision; the p1
-default is "mixed" (bf16 detector + fp16 recogniser): the cheapest arithmetic whose boxes AND decoded strings equalled the fp32 CPU
-path's on all 2,051 boxes of 64 distinct pages of THIS workload (tools/parity_sweep.py, profiles/r03_text_parity.json; plain bf16 gets
-1 string of 2,051 wrong), re-checked in every run by `parity_in_run`.  The LIBRARY's default is "fp16" (2-3 % slower: fp16 operands cost
-detector clock under the power limit): continuous-tone inputs (dense A4 scans, the reference's real images) need the fp16 detector
-(DESIGN.md section 4); its rate on this workload is `legs.fp16`.
+instead: 16 dense A4@300dpi scans (2480x3504) per GPU on the fp16 MFMA path.  `--precision` selects bbocr_config::precision; the
+default is "fp16" -- the LIBRARY's default, the one mode whose boxes and strings equalled the fp32 CPU path's on every input class
+measured (synthetic pages, dense A4 scans, the reference's real images).  "mixed" (bf16 detector, 2 % faster, loses
+boxes on continuous-tone inputs) runs as `legs.mixed`.  Every run re-checks identity with the CPU oracle (`parity_in_run`).
+
+Calls in flight: the reference shares ONE Reader between two ThreadPoolExecutor workers (batch_processor_enhanced.py:215); the timed
+region does the same -- `--in-flight 2` (default) worker threads call `readtext_device` on one Reader, libbbocr gives each call its own
+call slot, and batch k+1's detector is on the card while batch k's host thread does box geometry, CTC read-back and result export.
+Exactly K calls are timed either way; `legs.serial` is the one-call-at-a-time rate of rounds 1-3.
 
 Weights: the designed detector (bb_ocr_amd.weights.designed_craft_state) and the recogniser checkpoint trained on these
 synthetic pages (tests/golden/crnn_synth_fp16.npz, tests/golden/train_crnn.py) -- a recogniser that reads the pages has the
@@ -26,8 +29,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  -- the CPU oracle (restatement of the easyocr algorithm, kind "port") timed on this host, N=1 only.
   parity_in_run -- the SAME pages the CPU oracle just read, compared with what the timed GPU step returned for them:
                    boxes identical n/m, texts identical n/m.
-  legs          -- N=1 only, after the timed region: a few steps each of the other driver-visible modes
-                   (`--precision fp16` = the library default, `--precision exact`, `--config a4`), own readers, own roofline fractions.
+  legs          -- N=1 only, after the timed region, own readers: `serial` (one call in flight), `mixed`, `exact`, `a4_fp16` (configs[4] share),
+                   `det_only_b32_bf16` (configs[1], own roofline), `single_page` (the reference's real call: readtext(<jpeg path>), p50 / p95
+                   incl. decode + H2D), `host_pages` (64-page batches starting in pinned host memory, H2D overlapped), `lowconf` (faint-ink
+                   pages on which upstream's contrast retry is live, compared with the CPU oracle box by box).
   N > 1         -- ranks_seen, devices (per-rank PCI bus id / uuid, all-gathered; must be distinct under nccl),
                    weights_broadcast_ok (a failed broadcast is fatal unless --allow-local-weights).
 """
@@ -45,7 +50,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
 CRAFT_GFLOP_PER_PAGE = {"p1": 874.22, "a4": 3322.03}  # 1280x960 page / A4@300dpi on the 2560 canvas
 CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, line pitch, precision, workload label)
-    "p1": (1280, 960, 64, 24, 38, "mixed", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
+    "p1": (1280, 960, 64, 24, 38, "fp16", "full CRAFT+CRNN detect+recognize, batch=64 @1280x960 per GPU (BASELINE.json configs[2])"),
     "a4": (2480, 3504, 16, 110, 31, "fp16", "A4@300dpi 2480x3504 dense-text scans, fp16 MFMA conv path, 16 pages per GPU "
                                            "(BASELINE.json configs[4]: batch=128 on 8 GPUs)"),
 }
@@ -87,32 +92,38 @@ def render_pages(config, width, height, lines, first, count, unique):
     return [synth.page(1234 + (first + i), colour=bool((first + i) & 1), **kw)[0] for i in range(min(unique, count))]
 
 
-def timed_steps(reader, rgb, steps, warmup, dist=None, backend="nccl", rank=0, tag=""):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  -> (seconds, stage sums, last result)."""
+def timed_steps(reader, rgb, steps, warmup, dist=None, backend="nccl", rank=0, tag="", in_flight=2):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  -> (seconds, stage sums, last result).
+    `in_flight` worker threads share the Reader (the reference's ThreadPoolExecutor contract); a step = one readtext_device call."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import torch
 
     import bb_ocr_amd
 
-    for _ in range(warmup):
+    def one(_):
         out = reader.readtext_device(rgb, None)
-        log(f"{tag}warm-up step done: {reader.stage_times()}", rank)
-    reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
-    if os.environ.get("BBOCR_BENCH_NOFREEZE") != "1":
-        bb_ocr_amd.freeze_gc()   # host-process hygiene of a long-running OCR worker (see freeze_gc.__doc__)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stage, out = {}, None
-    for _ in range(steps):
-        out = reader.readtext_device(rgb, None)
-        for k, v in reader.stage_times().items():
-            stage[k] = stage.get(k, 0.0) + v
-        log(f"{tag}timed step done", rank)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+        return out, reader.stage_times()          # bbocr_stage_times answers for the calling thread
+
+    with ThreadPoolExecutor(max_workers=max(1, in_flight), thread_name_prefix="bench-call") as ex:
+        for out, st in ex.map(one, range(warmup)):
+            log(f"{tag}warm-up step done: {st}", rank)
+        reader.set_profiling(os.environ.get("BBOCR_BENCH_NOPROF") != "1")   # NOPROF: A/B of the event-recording overhead only
+        if os.environ.get("BBOCR_BENCH_NOFREEZE") != "1":
+            bb_ocr_amd.freeze_gc()   # host-process hygiene of a long-running OCR worker (see freeze_gc.__doc__)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stage, out = {}, None
+        for out, st in ex.map(one, range(steps)):
+            for k, v in st.items():
+                stage[k] = stage.get(k, 0.0) + v
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    log(f"{tag}{steps} timed steps done", rank)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,7 +168,7 @@ def device_identity(local_rank):
     return ident
 
 
-def run_leg(name, config, precision, steps, states, pages=None):
+def run_leg(name, config, precision, steps, states, pages=None, in_flight=2):
     """One of the other driver-visible modes on this card, after the main timed region: own reader; `pages` = the main run's rendered
     pages when the leg reads the same workload (else its own are rendered)."""
     import numpy as np
@@ -171,10 +182,10 @@ def run_leg(name, config, precision, steps, states, pages=None):
     try:
         uniq = pages if pages is not None else render_pages(config, cw, ch, cl, 0, cb, 4 if config == "a4" else cb)
         rgb = torch.from_numpy(np.stack([uniq[i % len(uniq)] for i in range(cb)])).cuda()
-        dt, stage, out = timed_steps(reader, rgb, steps, 1, tag=f"[leg {name}] ")
+        dt, stage, out = timed_steps(reader, rgb, steps, max(1, in_flight), tag=f"[leg {name}] ", in_flight=in_flight)
         rf = roofline(reader, config, cb, steps)
-        return {"metric": METRIC[config], "value": cb * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": 1,
-                "dtype": DTYPE[precision], "config": {"workload": workload, "precision": precision, "batch_per_gpu": cb,
+        return {"metric": METRIC[config], "value": cb * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": max(1, in_flight),
+                "dtype": DTYPE[precision], "config": {"workload": workload, "precision": precision, "batch_per_gpu": cb, "calls_in_flight": in_flight,
                                                       "boxes_per_step": sum(len(p) for p in out), "chars_per_step": sum(len(t) for p in out for _, t, _ in p)},
                 "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
                 "stage_ms_per_step": {k: v / steps for k, v in stage.items()}, "leg_seconds": time.perf_counter() - t_leg}
@@ -184,11 +195,165 @@ def run_leg(name, config, precision, steps, states, pages=None):
         torch.cuda.empty_cache()
 
 
+def leg_det_only(states, steps=5, batch=32):
+    """BASELINE.json configs[1]: CRAFT detection only, batch 32 synthetic 1280x960 pages, bf16, one card: pages -> heat-maps (bbocr_detect)."""
+    import numpy as np
+    import torch
+
+    import bb_ocr_amd
+
+    t_leg = time.perf_counter()
+    reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="bf16", recognizer=False)
+    try:
+        uniq = render_pages("p1", 1280, 960, 24, 0, batch, 8)
+        rgb = torch.from_numpy(np.stack([uniq[i % len(uniq)] for i in range(batch)])).cuda()
+        reader.heatmap_device(rgb)
+        reader.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            heat, _ = reader.heatmap_device(rgb)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rf = roofline(reader, "p1", batch, steps)
+        return {"metric": "CRAFT detection only, pages/sec @1280x960 (pages -> region/affinity heat-maps)", "value": batch * steps / dt, "unit": "images/s",
+                "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": 1, "dtype": "bf16",
+                "config": {"workload": "CRAFT detection only, batch=32 synthetic 1280x960 pages, bf16, 1 MI355X (BASELINE.json configs[1])", "batch_per_gpu": batch},
+                "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms")},
+                "leg_seconds": time.perf_counter() - t_leg}
+    finally:
+        reader.close()
+        del reader
+        torch.cuda.empty_cache()
+
+
+def leg_single_page(reader, pages, n=32):
+    """The reference's real call (enhanced_extractor.py:520): readtext(<jpeg path>, paragraph=False, batch_size=1, workers=0), one 1280x960 page per
+    call, file decode + H2D + detect + recognise + result marshalling inside the clock."""
+    import statistics
+    import tempfile
+
+    from PIL import Image
+
+    t_leg = time.perf_counter()
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i, pg in enumerate(pages[:8]):
+            paths.append(os.path.join(d, f"page{i}.jpg"))
+            Image.fromarray(pg).save(paths[-1], quality=95)
+        for pth in paths[:2]:
+            reader.readtext(pth, paragraph=False, batch_size=1, workers=0)
+        ms, dec, nb = [], [], 0
+        for i in range(n):
+            t0 = time.perf_counter()
+            res = reader.readtext(paths[i % len(paths)], paragraph=False, batch_size=1, workers=0)
+            ms.append((time.perf_counter() - t0) * 1e3)
+            nb += len(res)
+        from bb_ocr_amd.reader import decode_file
+        for i in range(8):
+            t0 = time.perf_counter()
+            decode_file(paths[i % len(paths)])
+            dec.append((time.perf_counter() - t0) * 1e3)
+    ms.sort()
+    return {"what": "Reader.readtext(<1280x960 JPEG path>, paragraph=False, batch_size=1, workers=0): the call at enhanced_extractor.py:520, one page per call, "
+                    "JPEG decode (PIL / libjpeg, host) + H2D + detect + recognise + result list inside the clock",
+            "calls": n, "p50_ms": statistics.median(ms), "p95_ms": ms[min(len(ms) - 1, int(0.95 * len(ms)))], "mean_ms": sum(ms) / len(ms),
+            "decode_only_p50_ms": statistics.median(dec), "boxes_per_page": nb / n, "precision": reader.precision, "leg_seconds": time.perf_counter() - t_leg}
+
+
+def leg_host_pages(reader, pages, batch, steps, resident_value, in_flight=2):
+    """Batches that START in pinned host memory: the H2D copy of batch k+1 (torch, own stream) runs while batch k is on the card
+    (Reader.readtext_stream drains its producer one batch ahead of the worker threads)."""
+    import numpy as np
+    import torch
+
+    t_leg = time.perf_counter()
+    host = torch.from_numpy(np.stack([pages[i % len(pages)] for i in range(batch)])).pin_memory()
+    copy_stream = torch.cuda.Stream()
+
+    def feed(k):
+        for _ in range(k):
+            with torch.cuda.stream(copy_stream):
+                dev = host.to("cuda", non_blocking=True)
+            copy_stream.synchronize()
+            yield dev
+
+    for _ in reader.readtext_stream(feed(in_flight), in_flight=in_flight):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nb = 0
+    for res in reader.readtext_stream(feed(steps), in_flight=in_flight):
+        nb += sum(len(pg) for pg in res)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    v = batch * steps / dt
+    return {"what": f"{steps} batches of {batch} pages, each starting in PINNED HOST memory ({host.numel() / 1e6:.0f} MB per batch): H2D on a copy stream one batch "
+                    f"ahead, {in_flight} calls in flight (Reader.readtext_stream); PCIe-inclusive, never the headline value",
+            "value": v, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "vs_resident": v / resident_value if resident_value else None,
+            "boxes_per_step": nb / steps, "leg_seconds": time.perf_counter() - t_leg}
+
+
+def leg_lowconf(reader, states, n_gpu_pages=16, n_cpu_pages=2, steps=3):
+    """Low-confidence workload: faint-ink lines (synth.page(faint=0.5)) whose first-pass confidence falls under contrast_ths = 0.1, so that
+    upstream's contrast retry (recognition.get_text: adjust_contrast_grey, second prediction, keep the better) is LIVE.  Timed on the card;
+    a few pages are also read by the CPU oracle: boxes / texts compared, and the retry DECISION (first-pass conf < contrast_ths) per box."""
+    import numpy as np
+    import torch
+
+    from bb_ocr_amd import synth
+    from oracle import imgproc, pipeline
+
+    t_leg = time.perf_counter()
+    kw = dict(width=1280, height=960, lines=24, line_pitch=38, margin=24, faint=0.5)
+    pages = [synth.page(9000 + i, **kw)[0] for i in range(n_gpu_pages)]
+    rgb = torch.from_numpy(np.stack(pages)).cuda()
+    out = reader.readtext_device(rgb, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    retry_ms = 0.0
+    for _ in range(steps):
+        out = reader.readtext_device(rgb, None)
+        retry_ms += reader.stage_times()["contrast_retry"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    first = reader.readtext_device(rgb[:n_cpu_pages].contiguous(), None, contrast_ths=0.0)       # first-pass confidences (no retry)
+    cs, rs = states
+    torch.set_num_threads(host_cores())
+    ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
+    boxes = same_box = same_text = low_ref = low_gpu = dec_diff = text_diff_same_decision = 0
+    for i in range(n_cpu_pages):
+        img, grey = imgproc.reformat_input(pages[i])
+        h, f = ref.detect(img)                                             # one detector pass on the CPU, two recogniser passes
+        want, want1 = ref.recognize(grey, h, f), ref.recognize(grey, h, f, contrast_ths=0.0)
+        got, got1 = out[i], first[i]
+        boxes += len(want)
+        for w, g, w1, g1 in zip(want, got, want1, got1):
+            b = np.array_equal(np.asarray(w[0], dtype=np.float64), np.asarray(g[0], dtype=np.float64))
+            dw, dg = float(w1[2]) < 0.1, float(g1[2]) < 0.1
+            same_box += b
+            same_text += w[1] == g[1]
+            low_ref += dw
+            low_gpu += dg
+            dec_diff += dw != dg
+            text_diff_same_decision += (dw == dg) and (w[1] != g[1])
+    n_all = sum(len(pg) for pg in out)
+    return {"what": "faint-ink pages (synth.page(faint=0.5): half of the lines a few grey levels from the paper in cv2's gray plane): upstream's contrast retry is "
+                    "live; the last timed step's result for the first pages vs oracle.pipeline.OracleReader.readtext, retry decision = first-pass conf < 0.1",
+            "precision": reader.precision, "value": n_gpu_pages * steps / dt, "unit": "images/s", "batch": n_gpu_pages, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "contrast_retry_ms_per_step": retry_ms / steps, "boxes_per_step": n_all,
+            "oracle_pages": n_cpu_pages, "boxes": boxes, "boxes_identical": f"{same_box}/{boxes}", "texts_identical": f"{same_text}/{boxes}",
+            "low_confidence_boxes_oracle": low_ref, "low_confidence_boxes_gpu": low_gpu, "retry_decisions_differing": dec_diff,
+            "texts_differing_with_equal_decision": text_diff_same_decision,
+            "all_identical": bool(same_box == boxes and same_text == boxes), "leg_seconds": time.perf_counter() - t_leg}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="p1", help="p1 = BASELINE.json configs[2]/[3] (the metric's workload), a4 = configs[4]")
     ap.add_argument("--batch", type=int, default=0, help="pages per GPU per step (0 = the config's)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic pages rendered per rank, tiled to --batch (0 = --batch: every page of the batch is its own page)")
@@ -198,8 +363,10 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
-    ap.add_argument("--legs", default="fp16,exact,a4", help="N=1: extra modes run after the timed region (comma list of fp16, mixed, bf16, exact, a4; '' = none)")
-    ap.add_argument("--leg-steps", type=int, default=3)
+    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf",
+                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf; '' = none)")
+    ap.add_argument("--leg-steps", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=2, help="calls in flight on the one Reader during the timed region (worker threads; bbocr_config::call_slots = 2)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 renders every rank's pages and scatters them (dist.scatter_pages: grouped "
                                                            "RCCL sends over xGMI) instead of every rank rendering its own shard; outside the timed region")
@@ -311,7 +478,7 @@ def main():
     torch.cuda.synchronize()
 
     log(f"pages resident: {tuple(rgb.shape)}; warm-up x{args.warmup}", rank)
-    dt, stage, out = timed_steps(reader, rgb, args.steps, args.warmup, dist, args.backend, rank)
+    dt, stage, out = timed_steps(reader, rgb, args.steps, args.warmup, dist, args.backend, rank, in_flight=args.in_flight)
     rf = roofline(reader, args.config, B, args.steps)
     n_boxes = sum(len(p) for p in out)
     n_chars = sum(len(t) for p in out for _, t, _ in p)
@@ -342,6 +509,7 @@ def main():
             "precision": args.precision,
             "batch_per_gpu": B, "page_wh": [args.width, args.height], "text_lines_per_page": args.lines,
             "boxes_per_step_rank0": n_boxes, "chars_per_step_rank0": n_chars, "parallelism": f"dp{world} (page shards, no data-path collective)",
+            "calls_in_flight": args.in_flight,
             "weights": weights_path, "pages": pages_path,
         },
         "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stage.items()},
@@ -353,18 +521,34 @@ def main():
         result["weights_broadcast_ok"] = broadcast_ok
     log(f"timed region done: {pages / dt:.1f} images/s", rank)
     if world == 1:
+        legs = {}
+        names = [n for n in args.legs.split(",") if n]
+        same = args.config == "p1" and (args.width, args.height, args.lines, args.batch) == CONFIGS["p1"][:2] + (CONFIGS["p1"][3], CONFIGS["p1"][2])
+        # legs that reuse the main reader (same weights, same precision) run before it is closed
+        if "single_page" in names and args.config == "p1":
+            legs["single_page"] = leg_single_page(reader, uniq)
+            log(f"leg single_page: p50 {legs['single_page']['p50_ms']:.2f} ms")
+        if "host_pages" in names and args.config == "p1":
+            legs["host_pages"] = leg_host_pages(reader, uniq, B, args.leg_steps, pages / dt, args.in_flight)
+            log(f"leg host_pages: {legs['host_pages']['value']:.1f} images/s")
+        if "lowconf" in names and args.rec_weights == "trained":
+            legs["lowconf"] = leg_lowconf(reader, (cs, rs))
+            log(f"leg lowconf: retry {legs['lowconf']['contrast_retry_ms_per_step']:.2f} ms per step, texts {legs['lowconf']['texts_identical']}")
         reader.close()
         del reader
         torch.cuda.empty_cache()
-        legs = {}
-        for name in [s for s in args.legs.split(",") if s]:
+        for name in names:
             if name in ("exact", "mixed", "fp16", "bf16") and not (args.config == "p1" and args.precision == name):
-                same = args.config == "p1" and (args.width, args.height, args.lines, args.batch) == CONFIGS["p1"][:2] + (CONFIGS["p1"][3], CONFIGS["p1"][2])
-                legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), uniq if same else None)
+                legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), uniq if same else None, args.in_flight)
+            elif name == "serial":
+                legs["serial"] = run_leg("serial", "p1", args.precision, args.leg_steps, (cs, rs), uniq if same else None, 1)
             elif name == "a4" and args.config != "a4":
-                legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs))
-            if legs:
-                log(f"leg {name}: {list(legs.values())[-1]['value']:.1f} images/s")
+                legs["a4_fp16"] = run_leg("a4_fp16", "a4", "fp16", args.leg_steps, (cs, rs), None, args.in_flight)
+            elif name == "det_only":
+                legs["det_only_b32_bf16"] = leg_det_only((cs, rs))
+            else:
+                continue
+            log(f"leg {name}: {list(legs.values())[-1]['value']:.1f} images/s")
         if legs:
             result["legs"] = legs
         if args.cpu_pages > 0:
@@ -400,6 +584,15 @@ def parity(ref_pages, gpu_pages, mode):
             "what": "oracle.pipeline.OracleReader.readtext (fp32 CPU) vs the last timed GPU step's result for the same pages: box coordinates equal as numbers, decoded strings equal"}
 
 
+def host_cores():
+    """the GPU box gives one GPU a 16-core share of the host; os.cpu_count() reports the whole machine"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, int(os.environ.get("BBOCR_CPU_THREADS", "16"))))
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -421,13 +614,7 @@ def cpu_baseline(cs, rs, pages, n_pages, wh):
 
     from oracle import pipeline
 
-    # the GPU box gives one GPU a 16-core share of the host; os.cpu_count() reports the whole machine
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("BBOCR_CPU_THREADS", "16"))))
-    torch.set_num_threads(cores)
+    torch.set_num_threads(host_cores())
     ref = pipeline.OracleReader({k: torch.from_numpy(v) for k, v in cs.items()}, {k: torch.from_numpy(v) for k, v in rs.items()})
     n = min(n_pages, len(pages))
     ref.readtext(pages[0])                                   # warm-up (thread pool, oneDNN primitive caches)

@@ -11,8 +11,10 @@
  * never aborts (the reference relies on catching exceptions: enhanced_extractor.py:529-531, i2j_ui/app/main.py:631-644);
  * bbocr_last_error() gives the message.  Image / heat-map pointers are DEVICE pointers (HBM); weight descriptors and
  * results are HOST memory.  All work of one call is ordered on the context's own HIP stream and the call returns after
- * that stream has drained.  One context may be used from several threads (calls serialise on an internal mutex);
- * ctypes releases the GIL around each call.
+ * its own work has finished.  One context may be used from several threads: up to bbocr_config::call_slots (default 2) pipeline
+ * calls run at once, each in its own call slot (work buffers, side stream), sharing the weights and the compute stream; further
+ * callers wait for a free slot; weight loading / export / import wait for every slot.  bbocr_stage_times and bbocr_last_error
+ * answer for the calling thread.  ctypes releases the GIL around each call.
  */
 #ifndef BBOCR_H
 #define BBOCR_H
@@ -57,7 +59,13 @@ typedef struct bbocr_config {
                          *                        toggle more bits under the power limit); on continuous-tone images its bf16
                          *                        heat-map flips a few threshold decisions (3 of 110 boxes on the reference's images).
                          * Any other value: bbocr_create returns BBOCR_ERR_ARG. */
-    int reserved[4];
+    int call_slots;     /* calls that may be IN FLIGHT on this context at once: 0 = default (2), 1 = calls serialise (rounds 1-3), 2.
+                         * The reference shares one Reader between ThreadPoolExecutor workers (batch_processor_enhanced.py:215, default 2).
+                         * A call that arrives while another is running takes the second slot: own work buffers (allocated on first use,
+                         * i.e. only if two calls ever overlap), same weights, same compute stream -- its detector runs on the card while the
+                         * first call's host thread finishes box geometry, CTC read-back and result export.  Results are those of the
+                         * serial path bit for bit (tests/test_gpu_pipeline.py::test_two_calls_in_flight_equal_the_serial_path). */
+    int reserved[3];
 } bbocr_config;
 enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2, BBOCR_PREC_MIXED = 3 };
 
@@ -169,7 +177,7 @@ int bbocr_readtext_batch(bbocr_ctx* ctx, const uint8_t* dev_rgb, const uint8_t* 
 void bbocr_free_boxlist(bbocr_boxlist* b);
 void bbocr_free_result(bbocr_result* r);
 
-/* milliseconds spent in the last readtext/detect/boxes/recognize call, per stage:
+/* milliseconds spent in the last readtext/detect/boxes/recognize call OF THE CALLING THREAD on this context, per stage:
  * [0] detector net (S2+S3), [1] CCL kernels (S4 device), [2] box geometry + grouping (S4/S5 host),
  * [3] crops (S6/S7), [4] recogniser net (S8), [5] CTC decode (S9), [6] contrast retry pass, [7] total */
 int bbocr_stage_times(bbocr_ctx* ctx, float* ms, int n);

@@ -541,6 +541,43 @@ def test_one_reader_called_from_worker_threads(reader):
     assert par == seq + seq
 
 
+def test_two_calls_in_flight_equal_the_serial_path(states):
+    """bbocr_config::call_slots: two worker threads share ONE Reader (batch_processor_enhanced.py:215) on full-size batches -- 24 pages of
+    1280x960 per call, detector passes [16, 8] with the early recogniser part -- and every call returns exactly what the same call returns
+    alone, whichever slot it ran in; distinct batches so that a buffer shared by mistake would show; stage times answer per thread; a
+    context created with call_slots = 1 (calls serialise, as in rounds 1-3) returns the same."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import bb_ocr_amd
+    from bb_ocr_amd import synth
+
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="fp16")
+    batches = [torch.from_numpy(np.stack([synth.page(40_000 + 100 * k + i, lines=6 + 4 * k + (i % 5), line_pitch=38, margin=24, colour=bool(i & 1))[0]
+                                          for i in range(24)])).cuda() for k in range(3)]
+    serial = [r.readtext_device(b) for b in batches]
+    assert all(sum(len(p) for p in s) > 100 for s in serial)
+    assert serial[0] != serial[1]
+
+    def call(k):
+        out = r.readtext_device(batches[k % 3])
+        return out, r.stage_times()
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        par = list(ex.map(call, range(8)))
+    for k, (out, st) in enumerate(par):
+        assert out == serial[k % 3], k
+        assert st["total"] > 0 and st["detector_net"] > 0
+    assert list(r.readtext_stream(iter(batches * 2))) == serial * 2                    # the streaming form: ordered results
+    # three callers on two slots: the third waits for a free slot
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        assert [o for o, _ in ex.map(call, range(6))] == (serial * 2)
+    r.close()
+    one = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="fp16", call_slots=1)
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        assert list(ex.map(lambda k: one.readtext_device(batches[k]), range(3))) == serial
+    one.close()
+
+
 def test_context_teardown_returns_device_memory(states):
     """Ownership: the context owns weights, work buffers, streams; close() gives all of it back.  Three create / use / close
     cycles (every optional buffer exercised: beam-search probabilities, rotation variants, the pre-processing planes) leave the free
