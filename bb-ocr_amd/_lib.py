@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("BBOCR_LIB_PATH") or os.path.join(_HERE, "libbbocr.so"
 
 class bbocr_config(C.Structure):
     _fields_ = [("device", C.c_int), ("det_sub_batch", C.c_int), ("rec_max_cols", C.c_int), ("precision", C.c_int), ("call_slots", C.c_int),
-                ("reserved", C.c_int * 3)]
+                ("host_threads", C.c_int), ("reserved", C.c_int * 2)]
 
 
 PRECISIONS = {"bf16": 0, "fp16": 1, "exact": 2, "mixed": 3}

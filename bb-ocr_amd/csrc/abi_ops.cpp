@@ -192,7 +192,7 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
         HIPCHK(hipMemcpyAsync(oo.data(), ctx->ctc_out.p, oo.size() * sizeof(CtcOut), hipMemcpyDeviceToHost, ctx->stream));
         if (beam) HIPCHK(hipMemcpyAsync(probs.data(), ctx->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         slot_sync(ctx, ctx->stream);
-        if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), n, C, cs, beam_width, beam_texts);
+        if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), n, C, cs, beam_width, beam_texts, &host_pool(ctx));
         int o = 0;
         for (int i = 0; i < n; ++i) {
             text_off[i] = o;

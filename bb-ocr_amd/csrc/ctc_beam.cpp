@@ -14,6 +14,7 @@
 //     order of the step's dictionary;
 //   * the result drops class 0 and every symbol equal to its predecessor in the labelling.
 #include "kernels.h"
+#include "hostpool.h"
 
 #include <algorithm>
 #include <atomic>
@@ -97,17 +98,9 @@ void ctc_beam_search_host(const float* mat, int T, int C, int cs, int beam_width
 }
 
 void ctc_beam_search_batch(const float* probs, const int* seqs /* {first row, T} per sequence */, int nseq, int C, int cs, int beam_width,
-                           std::vector<std::vector<int>>& texts) {
+                           std::vector<std::vector<int>>& texts, HostPool* pool) {
     texts.assign((size_t)nseq, {});
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nthreads = std::max(1, std::min({nseq, hw > 0 ? hw : 1, 16}));
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (int i = next.fetch_add(1); i < nseq; i = next.fetch_add(1))
-            ctc_beam_search_host(probs + (size_t)seqs[2 * i] * cs, seqs[2 * i + 1], C, cs, beam_width, texts[i]);
-    };
-    if (nthreads == 1) { work(); return; }
-    std::vector<std::thread> pool;
-    for (int i = 0; i < nthreads; ++i) pool.emplace_back(work);
-    for (auto& th : pool) th.join();
+    auto one = [&](int i) { ctc_beam_search_host(probs + (size_t)seqs[2 * i] * cs, seqs[2 * i + 1], C, cs, beam_width, texts[i]); };
+    if (pool) pool->parallel_for(nseq, one);
+    else for (int i = 0; i < nseq; ++i) one(i);
 }

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "boxpost.h"
+#include "hostpool.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -176,6 +178,7 @@ struct bbocr_ctx : WeightView {
     double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};   // root: totals
     long long prof_launches[2] = {0, 0};
 
+    std::unique_ptr<HostPool> pool;           // per slot, made on first use: host threads for box geometry / beam search (hostpool.h)
     std::vector<void*> owned;    // root: every hipMalloc'd weight block, in load order (the order of the weight blob, bbocr_weights_export)
     std::vector<size_t> owned_bytes;
 
@@ -322,6 +325,15 @@ unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint
 void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit);
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent, int threshold);
 void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const bbocr_preproc_params& q, uint8_t* out, int dh, int dw);
+
+// worker threads of this slot: bbocr_config::host_threads, or min(16, the process's CPU share); the pool is made once and kept
+inline HostPool& host_pool(bbocr_ctx* c) {
+    if (!c->pool) {
+        const int want = c->cfg.host_threads > 0 ? c->cfg.host_threads : std::min(16, host_cpu_share());
+        c->pool.reset(new HostPool(std::max(1, std::min(want, 64)) - 1));
+    }
+    return *c->pool;
+}
 
 // ---- call slots
 struct EnqLock {       // see bbocr_ctx::enq_mu; never held across a host wait for the device

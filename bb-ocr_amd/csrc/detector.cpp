@@ -399,26 +399,7 @@ void boxes_impl(bbocr_ctx* c, const float* heat, int B, int h, int w, double rat
         }
         bbocr::group_text_box(hb.polys[b], gp, hb.hori[b], hb.freeb[b]);
     };
-    const int nthr = std::max(1, std::min({B, 16, (int)std::thread::hardware_concurrency()}));
-    if (nthr <= 1) {
-        for (int b = 0; b < B; ++b) do_page(b);
-    } else {
-        std::atomic<int> next{0};
-        std::vector<std::thread> pool;
-        std::exception_ptr err;
-        std::mutex err_mu;
-        for (int t = 0; t < nthr; ++t)
-            pool.emplace_back([&] {
-                try {
-                    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) do_page(b);
-                } catch (...) {
-                    std::lock_guard<std::mutex> lk(err_mu);
-                    err = std::current_exception();
-                }
-            });
-        for (auto& th : pool) th.join();
-        if (err) std::rethrow_exception(err);
-    }
+    host_pool(c).parallel_for(B, do_page);      // the slot's persistent pool, sized from the process's CPU share (hostpool.h)
     c->times[2] += (float)ms_since(t0);
 }
 

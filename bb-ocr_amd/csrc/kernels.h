@@ -159,7 +159,9 @@ hipError_t launch_ctc(const float* logits, size_t rows, int C, int cs, const int
                       int* out_idx, CtcOut* out, hipStream_t s, const unsigned int* ignore = nullptr, float* probs_out = nullptr);   // ignore: 4 x 32-bit class mask or null
 // decoder='beamsearch' (easyocr/utils.py::ctcBeamSearch, host): probs fp32 [rows, cs] as ctc_rows_kernel writes them; seqs = {first row, T}
 void ctc_beam_search_host(const float* mat, int T, int C, int cs, int beam_width, std::vector<int>& text);
-void ctc_beam_search_batch(const float* probs, const int* seqs, int nseq, int C, int cs, int beam_width, std::vector<std::vector<int>>& texts);
+class HostPool;
+void ctc_beam_search_batch(const float* probs, const int* seqs, int nseq, int C, int cs, int beam_width, std::vector<std::vector<int>>& texts,
+                           HostPool* pool = nullptr);     // pool: the calling slot's workers (null: the calling thread alone)
 
 // ------------------------------------------------------------------ OCR pre-processing chain (preproc.hip), SURVEY 8 row f2
 hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const double* wx, const long long* nx,

@@ -270,7 +270,7 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
     c->times[4] += (float)ms_since(t0) - ctc_ms;     // host wait for the recogniser's device work (conv stack of the parts + sequence stage)
     c->times[5] += ctc_ms;                           // CTC kernels + read-back (device span) ...
     t0 = clk::now();                                 // ... + the host decode below
-    if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts);   // the confidence stays the greedy path's
+    if (beam) ctc_beam_search_batch(probs.data(), seqs.data(), nseq, 97, 112, c->beam_width, beam_texts, &host_pool(c));   // the confidence stays the greedy path's
     for (int i = 0; i < nseq; ++i) {
         const int k = run.seq_k[i];
         const size_t r0 = (size_t)seqs[2 * i];

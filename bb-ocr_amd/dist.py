@@ -64,32 +64,52 @@ def broadcast_packed(make_root_reader, make_empty_reader, src: int = 0, via_host
     import torch.distributed as dist
 
     rank = dist.get_rank()
-    reader = make_root_reader() if rank == src else make_empty_reader()
-    size = torch.tensor([reader.weights_blob_size()], dtype=torch.int64)
-    sizes = [torch.zeros_like(size) for _ in range(dist.get_world_size())]
-    if via_host:
-        dist.all_gather(sizes, size)
-    else:
-        size = size.to(reader.device)
-        sizes = [s.to(reader.device) for s in sizes]
-        dist.all_gather(sizes, size)
-    if len({int(s.item()) for s in sizes}) != 1:
-        raise RuntimeError("ranks disagree on the weight blob size: same precision and networks on every rank?")
-    if rank == src:
-        blob = reader.export_weights_blob()
-    else:
-        blob = torch.empty(reader.weights_blob_size(), dtype=torch.uint8, device=reader.device)
-    if via_host:
-        hb = blob.cpu()
-        dist.broadcast(hb, src=src)
-        if rank != src:
-            blob.copy_(hb)
+    # (1) construction is rank-local and may fail on ONE rank (out of memory, a missing checkpoint): agree on it before the first
+    # collective that assumes a reader everywhere -- otherwise the healthy ranks would sit in all_gather for ever
+    reader, err = None, None
+    try:
+        reader = make_root_reader() if rank == src else make_empty_reader()
+    except Exception as e:          # noqa: BLE001 -- reported below, on every rank
+        err = e
+    dev = "cpu" if (via_host or reader is None) else reader.device
+    if not via_host and reader is None:
+        dev = f"cuda:{torch.cuda.current_device()}"
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if reader is not None:
+            reader.close()
+        raise RuntimeError(f"reader construction failed on {'this rank: ' + repr(err) if err else 'another rank'}")
+    try:
+        size = torch.tensor([reader.weights_blob_size()], dtype=torch.int64)
+        sizes = [torch.zeros_like(size) for _ in range(dist.get_world_size())]
+        if via_host:
+            dist.all_gather(sizes, size)
+        else:
+            size = size.to(reader.device)
+            sizes = [s.to(reader.device) for s in sizes]
+            dist.all_gather(sizes, size)
+        if len({int(s.item()) for s in sizes}) != 1:
+            raise RuntimeError("ranks disagree on the weight blob size: same precision and networks on every rank?")
+        if rank == src:
+            blob = reader.export_weights_blob()
+        else:
+            blob = torch.empty(reader.weights_blob_size(), dtype=torch.uint8, device=reader.device)
+        if via_host:
+            hb = blob.cpu()
+            dist.broadcast(hb, src=src)
+            if rank != src:
+                blob.copy_(hb)
+                if blob.is_cuda:
+                    torch.cuda.current_stream(reader.device_index).synchronize()
+        else:
+            dist.broadcast(blob, src=src)                # ncclBroadcast, device to device over xGMI
             torch.cuda.current_stream(reader.device_index).synchronize()
-    else:
-        dist.broadcast(blob, src=src)                # ncclBroadcast, device to device over xGMI
-        torch.cuda.current_stream(reader.device_index).synchronize()
-    if rank != src:
-        reader.import_weights_blob(blob)
+        if rank != src:
+            reader.import_weights_blob(blob)
+    except Exception:
+        reader.close()              # the caller gets an exception, never a half-built reader: no second context / arena stays on the card
+        raise
     return reader
 
 

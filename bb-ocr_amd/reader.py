@@ -48,6 +48,18 @@ def _gray_bgr2gray(a: np.ndarray) -> np.ndarray:
     return ((a[..., 2] * 9798 + a[..., 1] * 19235 + a[..., 0] * 3735 + (1 << 14)) >> 15).astype(np.uint8)
 
 
+_DECODE_POOL = None
+
+
+def _decode_pool():
+    global _DECODE_POOL
+    if _DECODE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _DECODE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="bbocr-decode")
+    return _DECODE_POOL
+
+
 def decode_file(source):
     """What upstream's path branch holds after ``cv2.imread(path, IMREAD_GRAYSCALE)`` + ``loadImage(path)`` (skimage -> RGB):
     ``(rgb uint8 HWC, gray uint8 HW)``.  ONE stated rule for the gray plane, by container:
@@ -63,14 +75,21 @@ def decode_file(source):
         return Image.open(io.BytesIO(source)) if isinstance(source, (bytes, bytearray)) else Image.open(os.path.expanduser(str(source)))
 
     pil = _open()
-    rgb = np.ascontiguousarray(pil.convert("RGB"))
     if pil.format in ("JPEG", "MPO") and pil.mode in ("RGB", "YCbCr"):
-        y = _open()
-        y.draft("L", y.size)
-        grey = np.ascontiguousarray(y.convert("L"))
+        # two libjpeg passes over the same file (RGB, and the Y plane alone): side by side on two threads -- PIL releases the GIL
+        # while it decodes, so a page costs one decode time instead of two (the reference's call hands readtext a file PATH)
+        def _y_plane():
+            y = _open()
+            y.draft("L", y.size)
+            return np.ascontiguousarray(y.convert("L"))
+
+        fut = _decode_pool().submit(_y_plane)
+        rgb = np.ascontiguousarray(pil.convert("RGB"))
+        grey = fut.result()
         if grey.shape != rgb.shape[:2]:                      # draft() may not scale; keep the rule total
             grey = np.ascontiguousarray(pil.convert("L"))
         return rgb, grey
+    rgb = np.ascontiguousarray(pil.convert("RGB"))
     if pil.mode in ("L", "1"):
         return rgb, np.ascontiguousarray(pil.convert("L"))
     a = rgb.astype(np.int32)
@@ -208,7 +227,7 @@ class Reader:
     def __init__(self, lang_list, gpu=True, model_storage_directory=None, user_network_directory=None,
                  detect_network="craft", recog_network="standard", download_enabled=True, detector=True, recognizer=True,
                  verbose=True, quantize=True, cudnn_benchmark=False, weights=None, device_index=None, det_sub_batch=0,
-                 rec_max_cols=0, precision=None, call_slots=0, **_ignored):
+                 rec_max_cols=0, precision=None, call_slots=0, host_threads=None, **_ignored):
         import torch
 
         if list(lang_list) != ["en"]:
@@ -229,8 +248,13 @@ class Reader:
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
         self.precision = precision
+        if host_threads is None:
+            # ranks of one node share its cores: an un-pinned rank would otherwise size its host pool from the whole machine
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+            host_threads = 0 if local_world <= 1 else max(1, min(16, len(os.sched_getaffinity(0)) // local_world))
+        self.host_threads = int(host_threads)
         cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols),
-                                precision=_lib.PRECISIONS[precision], call_slots=int(call_slots))
+                                precision=_lib.PRECISIONS[precision], call_slots=int(call_slots), host_threads=self.host_threads)
         h = C.c_void_p()
         rc = self._lib.bbocr_create(C.byref(cfg), C.byref(h))
         if rc != 0:

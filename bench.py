@@ -412,6 +412,9 @@ def main():
     mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
     if os.environ.get("BBOCR_BENCH_INJECT") == "precision_mismatch" and rank == 1:     # tests/test_gpu_multirank.py: a broadcast that must fail
         mk = lambda w: bb_ocr_amd.Reader(["en"], gpu=True, weights=w, device_index=local_rank, precision="exact" if args.precision != "exact" else "bf16")
+    if os.environ.get("BBOCR_BENCH_INJECT") == "construct_fail_rank1" and rank == 1:       # a failure ONE rank sees (the others must not hang in a collective)
+        def mk(w):
+            raise MemoryError("injected: reader construction fails on rank 1 only")
     weights_path, broadcast_ok, devices = "local (single process)", None, None
     if world > 1:
         # who is here: every rank's card, all-gathered (a SCALE run can be checked for N distinct devices from the JSON alone)
@@ -437,13 +440,13 @@ def main():
                             f"{'RCCL, device to device' if args.backend == 'nccl' else args.backend + ' (host hop: rehearsal only)'} "
                             f"in {(time.perf_counter() - t_b) * 1e3:.0f} ms incl. packing")
         else:
-            if reader is not None:
-                reader.close()           # no second set of weights / second arena on the card
+            if reader is not None:       # (broadcast_packed closes the reader it built before it raises; a reader that came back is whole)
+                reader.close()
             if not args.allow_local_weights:
                 dist.destroy_process_group()
                 raise SystemExit("the packed weight broadcast failed on at least one rank; --allow-local-weights lets every rank build the seeded weights instead")
             cs, rs, weights_label = load_states(args.rec_weights)
-            reader = mk((cs, rs))
+            reader = bb_ocr_amd.Reader(["en"], gpu=True, weights=(cs, rs), device_index=local_rank, det_sub_batch=args.det_sub_batch, precision=args.precision)
             weights_path = "local on every rank (the packed broadcast FAILED; --allow-local-weights)"
     else:
         reader = mk((cs, rs))

@@ -65,7 +65,11 @@ typedef struct bbocr_config {
                          * i.e. only if two calls ever overlap), same weights, same compute stream -- its detector runs on the card while the
                          * first call's host thread finishes box geometry, CTC read-back and result export.  Results are those of the
                          * serial path bit for bit (tests/test_gpu_pipeline.py::test_two_calls_in_flight_equal_the_serial_path). */
-    int reserved[3];
+    int host_threads;   /* host worker threads per call slot (box geometry of a detector pass, beam search): 0 = auto = min(16, the CPUs this
+                         * PROCESS may use: scheduler affinity mask and cgroup CPU quota -- not the machine's core count, which every one of
+                         * the 8 ranks of a node would claim for itself).  Ranks that are not pinned pass their share (the Python host:
+                         * share / LOCAL_WORLD_SIZE).  The pool is created once per slot and kept; no thread is spawned per call. */
+    int reserved[2];
 } bbocr_config;
 enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2, BBOCR_PREC_MIXED = 3 };
 

@@ -78,3 +78,75 @@ def test_broadcast_scatter_gather(world):
         p.join(60)
         assert p.exitcode == 0
     assert res == {r: True for r in range(world)}
+
+
+class _FakeReader:
+    """Stands in for bb_ocr_amd.Reader in dist.broadcast_packed (the blob protocol only; no GPU in this container)."""
+
+    device, device_index = "cpu", 0
+
+    def __init__(self, fill):
+        self.blob = torch.full((4096,), fill, dtype=torch.uint8)
+        self.closed = False
+
+    def weights_blob_size(self):
+        return self.blob.numel()
+
+    def export_weights_blob(self):
+        return self.blob.clone()
+
+    def import_weights_blob(self, b):
+        self.blob = b.clone()
+
+    def close(self):
+        self.closed = True
+
+
+def _packed_worker(rank, world, port, q, fail_rank):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bb_ocr_amd import dist as bdist
+
+        built = []
+
+        def make(fill):
+            def f():
+                if rank == fail_rank:
+                    raise MemoryError("injected")
+                built.append(_FakeReader(fill))
+                return built[-1]
+            return f
+
+        try:
+            r = bdist.broadcast_packed(make(7), make(0), src=0, via_host=True)
+            q.put((rank, "ok", bool((r.blob == 7).all()), False))
+        except RuntimeError as e:
+            q.put((rank, "raised", "construction failed" in str(e), all(b.closed for b in built)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1, 0])
+def test_broadcast_packed_agrees_on_construction_before_the_first_collective(fail_rank):
+    """a reader that cannot be built on ONE rank ends broadcast_packed with an exception on EVERY rank (nobody waits in the size
+    all_gather), the readers that were built are closed; without a failure the receivers end up with the root's blob."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if fail_rank < 0:
+        assert res == {0: ("ok", True, False), 1: ("ok", True, False)}
+    else:
+        assert res == {0: ("raised", True, True), 1: ("raised", True, True)}

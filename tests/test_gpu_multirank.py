@@ -52,3 +52,20 @@ def test_failed_weight_broadcast_is_fatal():
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["weights_broadcast_ok"] is False and "FAILED" in d["config"]["weights"]
+
+
+def test_weight_broadcast_failing_on_one_rank_only_ends_every_rank():
+    """a rank-LOCAL failure (rank 1 cannot build its reader) must not leave rank 0 inside the size all_gather: the ranks agree on
+    construction before the first collective, the healthy rank's reader is closed, the run ends non-zero on both -- or, with
+    --allow-local-weights, continues on locally built weights and says so."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", BBOCR_BENCH_INJECT="construct_fail_rank1")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29545",
+            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--batch", "2", "--cpu-pages", "0"]
+    res = subprocess.run(base, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode != 0 and b"packed weight broadcast failed" in res.stderr and b"construction failed" in res.stderr
+    assert not [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    base[base.index("29545")] = "29546"
+    res = subprocess.run(base + ["--allow-local-weights"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["weights_broadcast_ok"] is False and "FAILED" in d["config"]["weights"] and d["ranks_seen"] == 2

@@ -253,3 +253,58 @@ def test_legacy_preprocess_fixtures_on_device(reader, n):
     got = dev_pp.preprocess_bgr_device(reader, torch.from_numpy(bgr).cuda(), legacy=True).cpu().numpy()
     assert np.array_equal(got, pp.preprocess_for_book_cover_legacy(bgr))
     assert int((got != want).sum()) == LEGACY_RESIDUAL[n]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, relu_out, pool_mode, pool_relu        (3x3 / pad 1: the layers launch_dma_one's `lean` rule picks)
+    (2, 32, 48, 64, 64, 1, 0, 0),        # 64-cout tile, interior tiles only: conv_epilogue_plain_lean<WHOLE>, `inside` fast path
+    (1, 19, 37, 64, 128, 1, 0, 0),       # 128-cout tile, ragged right / bottom edges (per-lane bounds tests)
+    (1, 21, 50, 128, 256, 0, 0, 0),      # two cout tiles, no ReLU: negative values stored as they are
+    (2, 32, 32, 128, 128, 1, 1, 0),      # conv_epilogue_pool2x2_lean on a 128-cout layer (conv3_3 / conv4_3 shape): pooled tensor only
+    (1, 32, 48, 64, 128, 0, 1, 1),       # pooled, pool_relu without relu_out (conv2_2's shape when the skip tensor is not kept)
+    (1, 18, 30, 64, 64, 1, 1, 0),        # pooled 64-cout, ragged
+])
+def test_lean_epilogues_equal_the_shared_epilogue_bit_for_bit(states, prec, cfg):
+    """the lean epilogues (packed-int16 ReLU on the rounded pair, max-before-bias pooling, whole-line regrouped stores) replace the
+    shared epilogue on most trunk layers.  The shared epilogue is what the SAME launch runs when it writes fp32 (out_f32 disables the lean
+    rule): its fp32 values, rounded to the element type with RNE (and max-pooled), must equal the lean launch's 16-bit output BIT FOR BIT --
+    both element types, ragged tiles, negative pre-ReLU values, pool_relu without relu_out."""
+    import bb_ocr_amd
+
+    N, H, W, Cin, Cout, relu_out, pool_mode, pool_relu = cfg
+    dtype = torch.bfloat16 if prec == "bf16" else torch.float16
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision=prec, recognizer=False)
+    try:
+        g = torch.Generator().manual_seed(1234 + Cout + H)
+        x = torch.randn(N, H, W, Cin, generator=g).to(dtype).cuda()
+        w = np.ascontiguousarray((torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)).numpy(), dtype=np.float32)
+        b = np.ascontiguousarray((torch.randn(Cout, generator=g) * 0.3).numpy(), dtype=np.float32)
+
+        def run(out_f32, pool):
+            full = torch.full((N, H, W, Cout), float("nan"), dtype=torch.float32 if out_f32 else dtype, device="cuda")
+            pooled = torch.full((N, H // 2, W // 2, Cout), float("nan"), dtype=dtype, device="cuda") if pool else None
+            rc = r._lib.bbocr_op_conv2d(r._h, C.c_void_p(x.data_ptr()), N, H, W, Cin, w.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                        Cout, 3, 3, 1, 1, 0, relu_out, int(out_f32), None if pool else C.c_void_p(full.data_ptr()), 1 if pool else 0, pool_relu,
+                                        C.c_void_p(pooled.data_ptr()) if pool else None)
+            r._check(rc)
+            return pooled if pool else full
+
+        ref32 = run(True, False)                                   # shared epilogue, fp32: bias (+ ReLU) on the raw accumulators
+        assert torch.isfinite(ref32).all() and (ref32 < 0).any() == (not relu_out)
+        if pool_mode:
+            want = F.max_pool2d(ref32.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            if pool_relu:
+                want = F.relu(want)
+            want = want.contiguous().to(dtype)                     # RNE; max and ReLU commute with the (monotone) rounding
+            got = run(False, True)
+        else:
+            want = ref32.to(dtype)
+            got = run(False, False)
+        assert got.shape == want.shape
+        gi, wi = got.view(torch.int16), want.view(torch.int16)
+        zero_sign = (gi != wi) & ((gi & 0x7fff) == 0) & ((wi & 0x7fff) == 0)       # +0 vs -0 cannot arise (acc + bias == -0 needs both -0): counted to be sure
+        assert int(zero_sign.sum()) == 0
+        assert torch.equal(gi, wi), f"{int((gi != wi).sum())} of {gi.numel()} values differ"
+    finally:
+        r.close()
