@@ -1,6 +1,16 @@
 // C ABI of libbbocr (include/bbocr.h): context life cycle, weights, the detect / boxes / recognise / readtext pipelines, pre-processing chain, profiling.
 #include "ctx.h"
 
+// the sequence stage's stream: highest priority, so that its few latency-bound workgroups are dispatched ahead of the other call's
+// thousands of conv workgroups whenever a CU frees up
+static hipError_t create_seq_stream(hipStream_t* s) {
+    static const bool prio = (diag_knob("BBOCR_SEQ_PRIO", 1) != 0);      // A/B knob
+    int lo = 0, hi = 0;
+    if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 extern "C" {
 
 void bbocr_default_params(bbocr_params* p) {
@@ -31,6 +41,7 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
         }
         if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+            create_seq_stream(&c->seq_stream) != hipSuccess ||
             hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
             delete c;
             return BBOCR_ERR_HIP;
@@ -56,7 +67,9 @@ bbocr_ctx* slot_create(bbocr_ctx* root) {
     if (own_stream) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     else s->stream = root->stream;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = create_seq_stream(&s->seq_stream);
     if (e != hipSuccess) {
+        if (s->stream2) (void)hipStreamDestroy(s->stream2);
         if (own_stream && s->stream) (void)hipStreamDestroy(s->stream);
         delete s;
         fail(BBOCR_ERR_HIP, std::string("call slot: ") + hipGetErrorString(e));
@@ -68,6 +81,8 @@ bbocr_ctx* slot_create(bbocr_ctx* root) {
 // per-slot resources (the root is slot 0): everything but the weights and the root's compute stream
 void slot_destroy(bbocr_ctx* c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->seq_stream) (void)hipStreamSynchronize(c->seq_stream);
+    if (c->feat_ev) (void)hipEventDestroy(c->feat_ev);
     for (hipEvent_t e : c->sub_events) (void)hipEventDestroy(e);
     if (c->det_t0) { (void)hipEventDestroy(c->det_t0); (void)hipEventDestroy(c->det_t1); }
     if (c->ccl_t0) { (void)hipEventDestroy(c->ccl_t0); (void)hipEventDestroy(c->ccl_t1); }
@@ -81,6 +96,7 @@ void slot_destroy(bbocr_ctx* c) {
                       &c->seq_tables, &c->pp_gray, &c->pp_a, &c->pp_b, &c->pp_c, &c->pp_tab, &c->ctc_probs};
     for (DevBuf* b : bufs) b->release();
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->seq_stream) (void)hipStreamDestroy(c->seq_stream);
     if (c->root != c) {
         if (c->stream && c->stream != c->root->stream) (void)hipStreamDestroy(c->stream);
         delete c;

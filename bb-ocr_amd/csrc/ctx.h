@@ -160,6 +160,10 @@ struct bbocr_ctx : WeightView {
     unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
     int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
     hipStream_t cur = nullptr;                // stream the layer helpers launch on
+    hipStream_t seq_stream = nullptr;         // per slot: the recogniser's SEQUENCE stage (projections, BiLSTMs, linears, CTC, read-back) -- latency-bound
+                                              // launches of 100-300 workgroups that leave most of the card idle -- runs here, behind an event of this
+                                              // slot's feature parts, so that it overlaps the OTHER call's detector instead of queueing in front of it
+    hipEvent_t feat_ev = nullptr;             // end of this slot's latest feature part on the compute stream
     hipStream_t stream2 = nullptr;            // box extraction of detector sub-batch k runs here while sub-batch k+1 is on `stream` (per slot)
     std::vector<hipEvent_t> sub_events;       // one per detector sub-batch of a readtext_batch call
     hipEvent_t ccl_t0 = nullptr, ccl_t1 = nullptr;   // GPU span of the CCL kernels of one boxes_impl call
@@ -358,6 +362,8 @@ inline void slot_sync(bbocr_ctx* c, hipStream_t st) {
 inline void guarded_drain(bbocr_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->seq_stream) (void)hipStreamSynchronize(ctx->seq_stream);
+    ctx->cur = ctx->stream;
     (void)hipGetLastError();
     for (auto& r : ctx->prof_recs) { ctx->prof_pool.push_back(r.e0); ctx->prof_pool.push_back(r.e1); }
     ctx->prof_recs.clear();

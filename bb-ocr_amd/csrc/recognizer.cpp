@@ -125,7 +125,7 @@ void crnn_sequence(bbocr_ctx* c, size_t rows_pad, const int* tiles_dev, int ntil
     Act cur{(uint16_t*)c->seq_v.p, 1, Hh, 256, 256 * m};
     for (int l = 0; l < 2; ++l) {
         run_conv(c, c->xproj[l], cur, false, nullptr, false, false, c->seq_xp.p, 2048, 2048, sp);
-        HIPCHK(launch_lstm(c->seq_xp.p, c->whh[l], (uint16_t*)c->seq_h.p, tiles_dev, ntiles, rec_mode(c), c->whh_scale[l], c->stream));
+        HIPCHK(launch_lstm(c->seq_xp.p, c->whh[l], (uint16_t*)c->seq_h.p, tiles_dev, ntiles, rec_mode(c), c->whh_scale[l], c->cur));
         Act hh{(uint16_t*)c->seq_h.p, 1, Hh, 256, 512 * m};
         uint16_t* dst = (uint16_t*)(l == 0 ? c->seq_lin.p : c->seq_v.p);
         run_conv(c, c->lin[l], hh, false, nullptr, false, false, dst, 256 * m, 256, false);
@@ -195,6 +195,8 @@ static void rec_launch_part(bbocr_ctx* c, const uint8_t* gray, int H, int W, con
         crnn_features_wide(c, wide, Wt, dd, 0, n, (uint16_t*)c->seq_v.p);
         if (pass == 0) c->arena.buf.ensure(c->arena.off);
     }
+    if (!c->feat_ev) HIPCHK(hipEventCreateWithFlags(&c->feat_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->feat_ev, c->stream));      // what the sequence stage (on seq_stream) waits for
 }
 
 static void rec_add_tables(RecRun& run, const RecPart& part, int tile_seqs) {
@@ -250,19 +252,27 @@ static void rec_finish(bbocr_ctx* c, RecRun& run, std::vector<std::vector<int>>&
     std::vector<std::vector<int>> beam_texts;
     if (!c->seq_t1) { HIPCHK(hipEventCreate(&c->seq_t1)); HIPCHK(hipEventCreate(&c->seq_t2)); }
     {
-        // sequence stage, CTC and the read-back of its results as ONE contiguous block on the compute stream and ONE host wait: with a
-        // second call in flight anything queued after a wait would land behind that call's whole detector
-        EnqLock enq(c);
-        HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        // Sequence stage, CTC and the read-back of its results: one block, ONE host wait.  It runs on the slot's own seq_stream behind the
+        // event of this slot's feature parts: its launches are latency chains of 100-300 workgroups (BiLSTM: 4.9 us per time step against
+        // 1 us of MFMA work) that leave most of the card idle -- with a second call in flight that call's detector fills it, instead of
+        // waiting in (or making this stage wait in) the compute stream's FIFO.
+        static const bool own = (diag_knob("BBOCR_SEQ_STREAM", 1) != 0);      // A/B knob
+        hipStream_t ss = (own && c->seq_stream && c->feat_ev) ? c->seq_stream : c->stream;
+        std::unique_lock<std::mutex> enq;
+        if (ss == c->stream) enq = std::unique_lock<std::mutex>(c->root->enq_mu);
+        else HIPCHK(hipStreamWaitEvent(ss, c->feat_ev, 0));
+        c->cur = ss;
+        struct Restore { bbocr_ctx* c; ~Restore() { c->cur = c->stream; } } restore{c};
+        HIPCHK(hipMemcpyAsync(tiles_dev, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ss));
+        HIPCHK(hipMemcpyAsync(seqs_dev, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, ss));
         crnn_sequence(c, rows_pad, tiles_dev, ntiles, (float*)c->seq_logits.p);
-        HIPCHK(hipEventRecord(c->seq_t1, c->stream));
+        HIPCHK(hipEventRecord(c->seq_t1, ss));
         HIPCHK(launch_ctc((const float*)c->seq_logits.p, rows, 97, 112, seqs_dev, nseq, (int*)c->ctc_idx.p, (float*)c->ctc_pmax.p,
-                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, c->stream, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
-        HIPCHK(hipMemcpyAsync(c->ctc_pin.p, c->ctc_out_idx.p, rows * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync((char*)c->ctc_pin.p + oo_off, c->ctc_out.p, (size_t)nseq * sizeof(CtcOut), hipMemcpyDeviceToHost, c->stream));
-        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(c->seq_t2, c->stream));
+                          (int*)c->ctc_out_idx.p, (CtcOut*)c->ctc_out.p, ss, c->ignore_mask, beam ? (float*)c->ctc_probs.p : nullptr));
+        HIPCHK(hipMemcpyAsync(c->ctc_pin.p, c->ctc_out_idx.p, rows * 4, hipMemcpyDeviceToHost, ss));
+        HIPCHK(hipMemcpyAsync((char*)c->ctc_pin.p + oo_off, c->ctc_out.p, (size_t)nseq * sizeof(CtcOut), hipMemcpyDeviceToHost, ss));
+        if (beam) HIPCHK(hipMemcpyAsync(probs.data(), c->ctc_probs.p, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ss));
+        HIPCHK(hipEventRecord(c->seq_t2, ss));
     }
     HIPCHK(hipEventSynchronize(c->seq_t2));
     float ctc_ms = 0.f;

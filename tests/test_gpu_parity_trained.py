@@ -215,3 +215,49 @@ def test_reference_photographs_through_the_zero_edit_hook(name, hook_readers, or
             assert all(abs(g[2] - float(w[2])) <= 1e-3 * max(float(w[2]), 1e-3) for g, w in zip(results, want))
         report[precision] = "identical"
     print(f"{name}: {len(want)} boxes ({n_free} free / rotated) vs the oracle: {report}")
+
+
+@pytest.mark.gpu
+def test_low_confidence_pages_with_the_contrast_retry_live(readers_trained, oracle_trained):
+    """upstream's retry (recognition.get_text: boxes with conf < contrast_ths = 0.1 are contrast-stretched, read again, the
+    better reading kept) reads the CONFIDENCE.  On faint-ink pages (synth.page(faint=0.5): half of the lines a few grey levels from the paper
+    in the gray plane) a third of the boxes take that branch.  `exact` reproduces the oracle completely -- boxes, retry decisions, final texts,
+    confidences; the default `fp16` mode returns the oracle's boxes, its retry DECISIONS may differ only where the oracle's first-pass
+    confidence lies within the mode's confidence error of 0.1, and its texts differ on at most a few of the (unreadable) faint boxes."""
+    from bb_ocr_amd import synth
+    from oracle import imgproc
+
+    kw = dict(width=1280, height=960, lines=24, line_pitch=38, margin=24, faint=0.5)
+    pages = [synth.page(9000 + i, **kw)[0] for i in range(2)]
+    rgb = torch.from_numpy(np.stack(pages)).cuda()
+    want, want1 = [], []
+    for p in pages:
+        img, grey = imgproc.reformat_input(p)
+        h, f = oracle_trained.detect(img)                                       # one detector pass on the CPU, two recogniser passes
+        want.append(oracle_trained.recognize(grey, h, f))
+        want1.append(oracle_trained.recognize(grey, h, f, contrast_ths=0.0))    # first-pass confidences: the retry disabled
+    n = sum(len(w) for w in want)
+    low = sum(float(b[2]) < 0.1 for w in want1 for b in w)
+    assert n >= 50 and low >= 0.2 * n, (n, low)                                 # the retry branch is live on >= 20 % of the boxes
+    report = {}
+    for mode in ("fp16", "exact"):
+        r = readers_trained[mode]
+        got = r.readtext_device(rgb)
+        assert r.stage_times()["contrast_retry"] > 0
+        got1 = r.readtext_device(rgb, contrast_ths=0.0)
+        dec_diff = text_diff = 0
+        for pw, pw1, pg, pg1 in zip(want, want1, got, got1):
+            assert len(pw) == len(pg) == len(pg1), mode
+            for w, w1, g, g1 in zip(pw, pw1, pg, pg1):
+                assert _same_box(w[0], g[0]), mode
+                cw, cg = float(w1[2]), float(g1[2])
+                if (cw < 0.1) != (cg < 0.1):
+                    dec_diff += 1
+                    assert mode != "exact" and abs(cw - 0.1) <= 0.3 * 0.1, (mode, cw, cg)    # only where the oracle itself sits at the threshold (CONF_BOUND)
+                text_diff += w[1] != g[1]
+                if mode == "exact":
+                    assert w[1] == g[1] and abs(float(w[2]) - g[2]) <= 1e-3 * max(float(w[2]), 1e-3)
+        report[mode] = {"retry_decisions_differing": dec_diff, "texts_differing": text_diff}
+        if mode == "fp16":
+            assert dec_diff <= max(1, n // 50) and text_diff <= max(2, n // 25), report
+    print(f"{n} boxes, {low} under contrast_ths on the first pass: {report}")
