@@ -68,6 +68,15 @@ PROTOTYPES = {
     "bbocr_weights_blob_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "bbocr_weights_export": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bbocr_weights_import": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "bbocr_dist_unique_id": (C.c_int, [_vp]),
+    "bbocr_dist_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "bbocr_dist_finalize": (C.c_int, [_vp]),
+    "bbocr_bcast_weights": (C.c_int, [_vp, C.c_int]),
+    "bbocr_scatter_images": (C.c_int, [_vp, _vp, C.c_longlong, C.c_size_t, C.c_int, _vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "bbocr_gather_results": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "bbocr_result_pack": (C.c_int, [C.POINTER(bbocr_result), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "bbocr_result_unpack": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.POINTER(bbocr_result))]),
+    "bbocr_free_bytes": (None, [_vp]),
     "bbocr_detect_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "bbocr_detect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(bbocr_params), _vp]),
@@ -80,6 +89,7 @@ PROTOTYPES = {
     "bbocr_stage_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "bbocr_set_profiling": (C.c_int, [_vp, C.c_int]),
     "bbocr_conv_profile": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "bbocr_host_cpu_share": (C.c_int, []),
     "bbocr_host_component_polys": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]),
     "bbocr_host_group_boxes": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(bbocr_params), C.POINTER(C.POINTER(bbocr_boxlist))]),
     "bbocr_host_ctc_beam": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1,10 +1,11 @@
 // C ABI of libbbocr (include/bbocr.h): context life cycle, weights, the detect / boxes / recognise / readtext pipelines, pre-processing chain, profiling.
 #include "ctx.h"
 
-// the sequence stage's stream: highest priority, so that its few latency-bound workgroups are dispatched ahead of the other call's
-// thousands of conv workgroups whenever a CU frees up
+// the sequence stage's stream.  (A HIGH-PRIORITY stream here -- so that its few latency-bound workgroups would be dispatched ahead of the
+// other call's thousands of conv workgroups -- was measured: the mere existence of a priority stream made every other stream of the
+// process slower, CCL 1.2 -> 2.3 ms, detector 53 -> 57 ms per step, 922 -> 873 images/s; profiles/r04_inflight_ab.txt.  Plain stream.)
 static hipError_t create_seq_stream(hipStream_t* s) {
-    static const bool prio = (diag_knob("BBOCR_SEQ_PRIO", 1) != 0);      // A/B knob
+    static const bool prio = (diag_knob("BBOCR_SEQ_PRIO", 0) != 0);      // A/B knob (diagnostic builds)
     int lo = 0, hi = 0;
     if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
@@ -120,6 +121,7 @@ void bbocr_destroy(bbocr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dist_release(c);
     for (bbocr_ctx* s : c->slots) slot_destroy(s);
     c->slots.clear();
     free_weights(c);

@@ -54,6 +54,8 @@ int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src,
     });
 }
 
+int bbocr_host_cpu_share(void) { return host_cpu_share(); }
+
 int bbocr_host_component_polys(const int* comps, const int* rowext, int n, int w, int h, double ratio, int* polys_out) {
     if (!comps || !rowext || !polys_out || n < 0 || w <= 0 || h <= 0 || !(ratio > 0)) return BBOCR_ERR_ARG;
     try {

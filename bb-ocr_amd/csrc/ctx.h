@@ -182,6 +182,8 @@ struct bbocr_ctx : WeightView {
     double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};   // root: totals
     long long prof_launches[2] = {0, 0};
 
+    void* dist_comm = nullptr;                // root: RCCL communicator of the bbocr_dist_* entry points (dist.cpp), or null
+    int dist_rank = 0, dist_world = 0;
     std::unique_ptr<HostPool> pool;           // per slot, made on first use: host threads for box geometry / beam search (hostpool.h)
     std::vector<void*> owned;    // root: every hipMalloc'd weight block, in load order (the order of the weight blob, bbocr_weights_export)
     std::vector<size_t> owned_bytes;
@@ -347,7 +349,8 @@ struct EnqLock {       // see bbocr_ctx::enq_mu; never held across a host wait f
 constexpr int kMaxSlots = 2;       // calls in flight per context (the reference runs 2 ThreadPoolExecutor workers on one Reader)
 bbocr_ctx* slot_create(bbocr_ctx* root);                 // abi.cpp
 void slot_destroy(bbocr_ctx* s);                         // abi.cpp (everything but the shared compute stream and the weights)
-void publish_times(const bbocr_ctx* s);                  // abi.cpp: the finished call's stage times -> the calling thread's record
+void publish_times(const bbocr_ctx* s);
+void dist_release(bbocr_ctx* root);                      // dist.cpp                  // abi.cpp: the finished call's stage times -> the calling thread's record
 
 // wait for what THIS slot has queued on `st` so far (the compute stream is shared between slots: hipStreamSynchronize would also wait for
 // the other call's kernels queued behind ours -- and the card would then run dry while both hosts wait)

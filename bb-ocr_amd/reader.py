@@ -221,6 +221,18 @@ def get_paragraph(raw_result, x_ths=1, y_ths=0.5, mode="ltr"):
     return result
 
 
+def auto_host_threads(local_world=None, cpus=None):
+    """``bbocr_config::host_threads`` for this process: 0 (the library sizes its pools from the process's own CPU share) unless several
+    ranks share the node un-pinned (torchrun sets LOCAL_WORLD_SIZE): then this rank's share of the CPUs it may run on, at most 16."""
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    if local_world <= 1:
+        return 0
+    if cpus is None:
+        cpus = len(os.sched_getaffinity(0))
+    return max(1, min(16, cpus // local_world))
+
+
 class Reader:
     """Drop-in for ``easyocr.Reader`` (English ``english_g2`` recogniser + CRAFT detector) on one MI355X."""
 
@@ -249,9 +261,7 @@ class Reader:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")      # see bbocr_config::precision (include/bbocr.h)
         self.precision = precision
         if host_threads is None:
-            # ranks of one node share its cores: an un-pinned rank would otherwise size its host pool from the whole machine
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
-            host_threads = 0 if local_world <= 1 else max(1, min(16, len(os.sched_getaffinity(0)) // local_world))
+            host_threads = auto_host_threads()
         self.host_threads = int(host_threads)
         cfg = _lib.bbocr_config(device=self.device_index, det_sub_batch=int(det_sub_batch), rec_max_cols=int(rec_max_cols),
                                 precision=_lib.PRECISIONS[precision], call_slots=int(call_slots), host_threads=self.host_threads)

@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
-    ap.add_argument("--cpu-pages", type=int, default=8, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
+    ap.add_argument("--cpu-pages", type=int, default=16, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
     ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf",
                     help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf; '' = none)")
     ap.add_argument("--leg-steps", type=int, default=4)

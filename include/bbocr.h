@@ -156,6 +156,30 @@ int bbocr_weights_blob_size(bbocr_ctx* ctx, size_t* bytes);
 int bbocr_weights_export(bbocr_ctx* ctx, void* dev_blob, size_t bytes);
 int bbocr_weights_import(bbocr_ctx* ctx, const void* dev_blob, size_t bytes);
 
+/* ---- multi-GPU for hosts without torch.distributed: one process per GPU, RCCL over xGMI ----
+ * The Python host reaches RCCL through torch.distributed (bb-ocr_amd/dist.py); these entry points do the same exchanges from C.  RCCL is
+ * loaded with dlopen("librccl.so.1") at the first call, so single-GPU users need no RCCL.  Rank 0 makes the 128-byte id
+ * (bbocr_dist_unique_id = ncclGetUniqueId) and hands it to the other ranks out of band (environment, file, socket); every rank then
+ * calls bbocr_dist_init (ncclCommInitRank: collective).  All of them are collective over the ranks of the communicator and wait for every
+ * call slot of the context.  There is no collective inside the OCR path itself: pages are independent.
+ *   bbocr_bcast_weights   ONE ncclBroadcast of the packed weight blob (root: bbocr_load_weights; others: bbocr_alloc_weights, same
+ *                         precision) -- replaces nn.DataParallel's per-forward broadcast_coalesced (easyocr.py::get_detector / get_recognizer);
+ *   bbocr_scatter_images  the loader rank's units (pages of unit_bytes = H*W*3) -> each rank's contiguous block [first, first + count)
+ *                         (block partition, uneven / empty blocks allowed) as one grouped batch of ncclSend: the root's links carry all
+ *                         blocks at once; dev_local holds ceil(n_units / world) units;
+ *   bbocr_gather_results  per-rank host bytes (bbocr_result_pack of the rank's results) -> on root one malloc'd concatenation in rank
+ *                         order (*all, free with bbocr_free_bytes) + sizes[world]; bbocr_result_unpack rebuilds each bbocr_result. */
+int bbocr_dist_unique_id(void* id128);
+int bbocr_dist_init(bbocr_ctx* ctx, int rank, int world, const void* id128);
+int bbocr_dist_finalize(bbocr_ctx* ctx);
+int bbocr_bcast_weights(bbocr_ctx* ctx, int root);
+int bbocr_scatter_images(bbocr_ctx* ctx, const uint8_t* dev_all, long long n_units, size_t unit_bytes, int root, uint8_t* dev_local, long long* first,
+                         long long* count);
+int bbocr_gather_results(bbocr_ctx* ctx, const void* local, size_t local_bytes, int root, void** all, size_t* sizes);
+int bbocr_result_pack(const bbocr_result* r, void** bytes, size_t* n);       /* free *bytes with bbocr_free_bytes */
+int bbocr_result_unpack(const void* bytes, size_t n, bbocr_result** out);    /* free *out with bbocr_free_result */
+void bbocr_free_bytes(void* p);
+
 /* geometry of the detector for an H x W page: network input H32 x W32 (after canvas_size scaling, padded to x32),
  * heat-map h x w = H32/2 x W32/2, ratio as returned by resize_aspect_ratio */
 int bbocr_detect_dims(int H, int W, int canvas_size, double mag_ratio, int* H32, int* W32, int* rh, int* rw, double* ratio);
@@ -197,6 +221,9 @@ int bbocr_conv_profile(bbocr_ctx* ctx, int group, double* ms, double* flops, lon
  * comps: [n][7] = root, left, top, right, bottom, area, row_off (heat-map coordinates); rowext: per component row the
  * min/max x of TEXT pixels ([row_off + y - top][2], max < 0 = none) -- exactly what the CCL kernels emit.
  * Writes n polygons [n][8] (craft_utils.getDetBoxes_core tail + adjustResultCoordinates + get_textbox). */
+/* CPUs this PROCESS may use (scheduler affinity mask, cgroup v2 cpu.max / v1 cfs quota): what bbocr_config::host_threads = 0 sizes the
+ * per-slot host pools from (capped at 16) -- never the machine's core count */
+int bbocr_host_cpu_share(void);
 int bbocr_host_component_polys(const int* comps, const int* rowext, int n, int w, int h, double ratio, int* polys_out);
 /* utils.group_text_box + Reader.detect's min_size filter on n polygons of one image */
 int bbocr_host_group_boxes(const int* polys, int n, const bbocr_params* p, bbocr_boxlist** out);

@@ -447,3 +447,54 @@ def test_output_formats():
     assert format_output(para, "dict", paragraph=True)[0] == {"boxes": res[0][0], "text": "ab"}
     with pytest.raises(NotImplementedError):
         format_output(res, "free_merge")
+
+
+def test_result_pack_unpack_round_trip_and_dist_entry_points_without_a_communicator(lib):
+    """The bytes bbocr_gather_results moves between ranks: bbocr_result -> flat block -> bbocr_result, field for field; a block whose header
+    does not match its length or its offsets is refused; the RCCL entry points are status codes, not crashes, on a null context."""
+    from bb_ocr_amd import _lib
+
+    box_off = (C.c_int * 3)(0, 2, 3)
+    quads = (C.c_double * 24)(*[float(i) * 0.5 for i in range(24)])
+    is_free = (C.c_int * 3)(0, 1, 0)
+    text_off = (C.c_int * 4)(0, 2, 2, 5)
+    text_idx = (C.c_int * 5)(11, 12, 40, 41, 96)
+    conf = (C.c_double * 3)(0.9, 0.0, 0.25)
+    r = _lib.bbocr_result(n_images=2, box_off=box_off, quads=quads, is_free=is_free, text_off=text_off, text_idx=text_idx, conf=conf)
+    blob, n = C.c_void_p(), C.c_size_t()
+    assert lib.bbocr_result_pack(C.byref(r), C.byref(blob), C.byref(n)) == 0 and n.value > 0
+    out = C.POINTER(_lib.bbocr_result)()
+    assert lib.bbocr_result_unpack(blob, n.value, C.byref(out)) == 0
+    o = out.contents
+    assert o.n_images == 2 and [o.box_off[i] for i in range(3)] == [0, 2, 3]
+    assert [o.quads[i] for i in range(24)] == [float(i) * 0.5 for i in range(24)]
+    assert [o.is_free[i] for i in range(3)] == [0, 1, 0] and [o.text_off[i] for i in range(4)] == [0, 2, 2, 5]
+    assert [o.text_idx[i] for i in range(5)] == [11, 12, 40, 41, 96] and [o.conf[i] for i in range(3)] == [0.9, 0.0, 0.25]
+    lib.bbocr_free_result(out)
+    bad = C.POINTER(_lib.bbocr_result)()
+    assert lib.bbocr_result_unpack(blob, n.value - 4, C.byref(bad)) == -1                      # truncated
+    raw = (C.c_char * n.value).from_address(blob.value)
+    raw[8] = 7                                                                            # header says 7 boxes, offsets say 3
+    assert lib.bbocr_result_unpack(blob, n.value, C.byref(bad)) == -1
+    lib.bbocr_free_bytes(blob)
+    assert lib.bbocr_dist_init(None, 0, 1, None) == -1 and lib.bbocr_bcast_weights(None, 0) == -1
+    assert lib.bbocr_gather_results(None, None, 0, 0, None, None) == -1 and lib.bbocr_dist_finalize(None) == -1
+
+
+def test_host_pools_are_sized_from_the_process_share_not_the_machine(lib):
+    """eight ranks on one host must not each claim every core.  The library sizes its per-slot host pools from the CPUs the
+    PROCESS may use (affinity mask / cgroup quota); the Python host divides an un-pinned rank's share by LOCAL_WORLD_SIZE."""
+    import subprocess
+
+    from bb_ocr_amd.reader import auto_host_threads
+
+    here = len(os.sched_getaffinity(0))
+    assert 1 <= lib.bbocr_host_cpu_share() <= here
+    if here >= 2:      # a child pinned to two CPUs sees a share of two, whatever the machine has
+        code = ("import os, sys; os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:2]); sys.path.insert(0, %r); "
+                "from bb_ocr_amd import _lib; print(_lib.load().bbocr_host_cpu_share())" % ROOT)
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip() == b"2", out.stderr.decode()[-500:]
+    assert auto_host_threads(1, 128) == 0                       # single process: the library's own rule
+    assert auto_host_threads(8, 128) == 16 and auto_host_threads(8, 64) == 8 and auto_host_threads(8, 4) == 1
+    assert sum(auto_host_threads(8, 96) for _ in range(8)) <= 96       # eight ranks together stay within the host

@@ -69,3 +69,51 @@ def test_weight_broadcast_failing_on_one_rank_only_ends_every_rank():
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["weights_broadcast_ok"] is False and "FAILED" in d["config"]["weights"] and d["ranks_seen"] == 2
+
+
+def test_rccl_entry_points_of_the_c_abi_with_a_one_rank_communicator(tmp_path):
+    """include/bbocr.h bbocr_dist_*: the C-side RCCL path (dlopen'd librccl, ncclCommInitRank, all-gather of sizes, broadcast, grouped
+    send / recv, result gather) on the one card of this box: a communicator of ONE rank (RCCL refuses two ranks on one device).  Run in a
+    child process: RCCL initialises its own state and this pytest process already holds torch's.  The weight blob survives the broadcast,
+    the scatter hands the rank its whole block, the gathered bytes unpack to the results that went in."""
+    script = tmp_path / "one_rank.py"
+    script.write_text('''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import bb_ocr_amd
+from bb_ocr_amd import _lib, synth, weights
+lib = _lib.load()
+r = bb_ocr_amd.Reader(["en"], gpu=True, weights=(weights.designed_craft_state(0), weights.synthetic_crnn_state(0)), precision="fp16")
+img = synth.page(5, width=320, height=192, lines=3, margin=24)[0]
+want = r.readtext(img)
+uid = (C.c_char * 128)()
+assert lib.bbocr_dist_unique_id(uid) == 0
+r._check(lib.bbocr_dist_init(r._h, 0, 1, uid))
+assert lib.bbocr_dist_init(r._h, 0, 1, uid) == -4                     # one communicator per context
+r._check(lib.bbocr_bcast_weights(r._h, 0))
+assert r.readtext(img) == want                                       # the weights are what they were
+pages = torch.from_numpy(np.stack([img, img[::-1].copy(), img[:, ::-1].copy()])).cuda()
+local = torch.zeros_like(pages)
+first, count = C.c_longlong(-1), C.c_longlong(-1)
+r._check(lib.bbocr_scatter_images(r._h, C.c_void_p(pages.data_ptr()), 3, img.size, 0, C.c_void_p(local.data_ptr()), C.byref(first), C.byref(count)))
+assert (first.value, count.value) == (0, 3) and torch.equal(local, pages)
+res = C.POINTER(_lib.bbocr_result)()
+p = _lib.bbocr_params(); lib.bbocr_default_params(C.byref(p))
+r._check(lib.bbocr_readtext_batch(r._h, C.c_void_p(local.data_ptr()), None, 3, img.shape[0], img.shape[1], C.byref(p), C.byref(res)))
+blob, n = C.c_void_p(), C.c_size_t()
+assert lib.bbocr_result_pack(res, C.byref(blob), C.byref(n)) == 0
+allp, sizes = C.c_void_p(), (C.c_size_t * 1)()
+r._check(lib.bbocr_gather_results(r._h, blob, n.value, 0, C.byref(allp), sizes))
+assert sizes[0] == n.value and C.string_at(allp.value, n.value) == C.string_at(blob.value, n.value)
+back = C.POINTER(_lib.bbocr_result)()
+assert lib.bbocr_result_unpack(allp, sizes[0], C.byref(back)) == 0
+assert r._collect(back)[0] == want and len(r._collect(res)) == 3
+lib.bbocr_free_bytes(blob); lib.bbocr_free_bytes(allp)
+r._check(lib.bbocr_dist_finalize(r._h))
+r.close()
+print("ONE_RANK_OK")
+''' % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0 and b"ONE_RANK_OK" in res.stdout, res.stderr.decode()[-3000:]

@@ -261,3 +261,22 @@ def test_low_confidence_pages_with_the_contrast_retry_live(readers_trained, orac
         if mode == "fp16":
             assert dec_diff <= max(1, n // 50) and text_diff <= max(2, n // 25), report
     print(f"{n} boxes, {low} under contrast_ths on the first pass: {report}")
+
+
+@pytest.mark.gpu
+def test_default_mode_equals_the_oracle_on_sixteen_more_pages(readers_trained, oracle_trained):
+    """a wider driver-visible comparison of the LIBRARY DEFAULT (fp16) with the fp32 CPU oracle: 16 further full-size bench
+    pages (disjoint from the four above and from bench.py's parity_in_run pages), ~45 s of oracle time: every box and every decoded string
+    identical, zero tolerance."""
+    pages = _bench_pages(16, first=100)
+    rgb = torch.from_numpy(np.stack([p[0] for p in pages])).cuda()
+    got = readers_trained["fp16"].readtext_device(rgb)
+    n = bad_box = bad_text = 0
+    for (img, _), pg in zip(pages, got):
+        pw = oracle_trained.readtext(img)
+        assert len(pw) == len(pg)
+        n += len(pw)
+        bad_box += sum(not _same_box(w[0], g[0]) for w, g in zip(pw, pg))
+        bad_text += sum(w[1] != g[1] for w, g in zip(pw, pg))
+    print(f"fp16 (library default) vs the fp32 oracle on 16 pages: {n} boxes, {bad_box} boxes / {bad_text} texts differ")
+    assert n > 400 and bad_box == 0 and bad_text == 0

@@ -286,34 +286,20 @@ def test_crnn_logits_within_tolerance(reader, oracle_reader):
         assert rel < 3e-2, rel
 
 
-def _edit_distance(a, b):
-    prev = list(range(len(b) + 1))
-    for i, ca in enumerate(a, 1):
-        cur = [i]
-        for j, cb in enumerate(b, 1):
-            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
-        prev = cur
-    return prev[-1]
-
-
 def test_readtext_end_to_end(reader, oracle_reader):
-    """Whole path on designed-weight pages: boxes identical to the oracle's; text compared per character."""
+    """Whole path on designed-weight pages: boxes identical to the oracle's, one result per box, confidences are probabilities.  (The recogniser
+    of this fixture has RANDOM weights: what its text must satisfy is asserted per time step, against the oracle's own top-2 margins, in
+    tests/test_gpu_precision.py::test_readtext_text_identity_by_mode; text identity with hard counts is tests/test_gpu_parity_trained.py.)"""
     from bb_ocr_amd import synth
 
-    agree = total = 0
     for seed in (101, 102):
         img = synth.page(seed, width=512, height=320, lines=6, margin=24)[0]
         got = reader.readtext(img)
         want = oracle_reader.readtext(img)
         assert [g[0] for g in got] == [[list(map(int, p)) for p in w[0]] for w in want]
-        for (_, tg, cg), (_, tw, cw) in zip(got, want):
-            total += max(len(tg), len(tw))
-            agree += max(len(tg), len(tw)) - _edit_distance(tg, tw)
-        assert len(got) >= 4
-    # random-weight recogniser in bf16 vs fp32: arg-max flips happen where the top-2 margin is below the bf16 noise,
-    # so text identity is statistical here; the exact checks are the stage tests (CTC given logits, boxes given heat-map)
-    # text identity per precision mode (margin-aware for bf16 / fp16, outright for the exact mode): tests/test_gpu_precision.py
-    print("bf16 character agreement with the fp32 oracle (edit distance):", agree, "of", total)
+        assert len(got) >= 4 and all(isinstance(t, str) and 0.0 <= c <= 1.0 for _, t, c in got)
+        # same number of decoded characters give or take the arg-max flips of a margin-less recogniser: the sequence lengths (T per box) agree
+        assert all(abs(len(tg) - len(tw)) <= max(4, len(tw) // 2) for (_, tg, _), (_, tw, _) in zip(got, want))
 
 
 def test_readtext_edge_pages(reader, oracle_reader):
