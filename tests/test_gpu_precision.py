@@ -240,7 +240,7 @@ def test_weight_blob_export_import(states, precision):
         b.close()
 
 
-def test_a4_batch16_fp16_properties(reader_fp16, reader, oracle_reader):
+def test_a4_batch16_fp16_properties(reader_fp16, reader, reader_exact, oracle_reader):
     """BASELINE.json configs[4] per-GPU share on the fp16 MFMA path: 16 dense A4@300dpi scans (2480x3504 -> canvas 1824x2560, the resize
     path at full size) in one call.  Size-independent properties: copies of a page agree, a page's result does not depend on its batch,
     no page-height box arises from the black canvas stripe, fp16 and bf16 find the same boxes; and one page against the oracle's
@@ -271,18 +271,22 @@ def test_a4_batch16_fp16_properties(reader_fp16, reader, oracle_reader):
     assert [list(map(int, p)) for p in op] == polys[0] and [list(map(int, b)) for b in oh] == hori[0] and len(of) == len(free[0])
     # against the oracle's own fp32 detector (one CRAFT forward on the CPU, ~15 s per page): box indices are integer outputs -- the fp16 path
     # returns the oracle's boxes EXACTLY (grouped and free, same order), on two pages, and none of the threshold decisions flips
+    # ... and so does the exact mode's split-fp16 detector (round 4), whose heat-maps follow the oracle's to ~1e-5 on the canvas-resized scan
     for k in (1, 2):
-        heat, ratio = reader_fp16.heatmap_device(rgb[k:k + 1])
-        hori, free, polys = reader_fp16.boxes_from_heatmap(heat, ratio)
         st, sl, r2 = oracle_reader.heatmap(uniq[k])
         oh, of, op = obox.detect_from_heatmap(st, sl, r2)
-        hh = heat[0].cpu().numpy()
-        flips = int(((hh[..., 0] > 0.4) != (st > 0.4)).sum() + ((hh[..., 1] > 0.4) != (sl > 0.4)).sum())
-        print(f"A4 page {k}, fp16 vs the fp32 oracle detector: {flips} threshold flips, {len(oh)} grouped + {len(of)} free boxes")
-        assert flips == 0 and ratio == r2
-        assert [list(map(int, p)) for p in op] == polys[0]
-        assert [list(map(int, b)) for b in oh] == hori[0]
-        assert len(of) == len(free[0]) and all(np.array_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)) for a, b in zip(of, free[0]))
+        for name, rd in (("fp16", reader_fp16), ("exact", reader_exact)):
+            heat, ratio = rd.heatmap_device(rgb[k:k + 1])
+            hori, free, polys = rd.boxes_from_heatmap(heat, ratio)
+            hh = heat[0].cpu().numpy()
+            flips = int(((hh[..., 0] > 0.4) != (st > 0.4)).sum() + ((hh[..., 1] > 0.4) != (sl > 0.4)).sum())
+            err = max(float(np.abs(hh[..., 0] - st).max()), float(np.abs(hh[..., 1] - sl).max()))
+            print(f"A4 page {k}, {name} vs the fp32 oracle detector: {flips} threshold flips, max |heat error| {err:.2e}, {len(oh)} grouped + {len(of)} free boxes")
+            assert flips == 0 and ratio == r2, name
+            assert name != "exact" or err < 5e-5
+            assert [list(map(int, p)) for p in op] == polys[0], name
+            assert [list(map(int, b)) for b in oh] == hori[0], name
+            assert len(of) == len(free[0]) and all(np.array_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)) for a, b in zip(of, free[0])), name
 
 
 def test_noise_sensitive_detector_flip_rates(reader, reader_fp16):
