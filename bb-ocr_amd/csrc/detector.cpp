@@ -20,7 +20,8 @@ hipError_t launch_conv_profiled(bbocr_ctx* c, const ConvPlan& p, ConvArgs a, boo
     r.e0 = get_event();
     r.e1 = get_event();
     const int OH = a.H + 2 * p.pad_h - (p.KH - 1) * p.dil, OW = a.W + 2 * p.pad_w - (p.KW - 1) * p.dil;
-    r.flops = 2.0 * a.N * OH * OW * (double)p.Cout * p.Cin * p.KH * p.KW;   // algorithmic (unpadded) work
+    r.flops = 2.0 * a.N * OH * OW * (double)p.Cout * (p.split ? p.Cin / 3 : p.Cin) * p.KH * p.KW;   // algorithmic (unpadded) work; a split-fp16 plan
+                                                                                                     // executes three product terms per MAC: counted once
     if (a.c11_w) r.flops += 2.0 * a.N * a.H * a.W * 64.0 * 27.0;            // conv1_1 produced inside this launch
     if (a.tail) r.flops += 2.0 * a.N * OH * OW * (16.0 * 16.0 + 16.0 * 2.0);   // fused classifier tail
     if (a.post_w) r.flops += 2.0 * a.N * OH * OW * 64.0 * 64.0;                 // 1x1 applied in the epilogue

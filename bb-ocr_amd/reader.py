@@ -530,19 +530,25 @@ class Reader:
         return [h[0]], [f[0]]
 
     def recognize(self, img_cv_grey, horizontal_list=None, free_list=None, decoder="greedy", beamWidth=5, detail=1, paragraph=False,
-                  contrast_ths=0.1, adjust_contrast=0.5, reformat=True, rotation_info=None, **_ignored):
-        """``Reader.recognize`` for explicit boxes of one gray page."""
-        self._unsupported(decoder, None, None, None, False, "standard")
+                  contrast_ths=0.1, adjust_contrast=0.5, reformat=True, rotation_info=None, allowlist=None, blocklist=None, y_ths=0.5, x_ths=1.0,
+                  output_format="standard", **_ignored):
+        """``Reader.recognize`` for explicit boxes of one gray page (``paragraph=True``: ``get_paragraph`` on the result, like upstream)."""
+        self._unsupported(decoder, None, None, None, False, output_format)
         if paragraph:
-            raise NotImplementedError("recognize(paragraph=True) is not implemented; readtext(paragraph=True) is")
+            raw = self.recognize(img_cv_grey, horizontal_list, free_list, decoder=decoder, beamWidth=beamWidth, detail=1, paragraph=False,
+                                 contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, reformat=reformat, rotation_info=rotation_info,
+                                 allowlist=allowlist, blocklist=blocklist)
+            para = get_paragraph(raw, x_ths=x_ths, y_ths=y_ths, mode="ltr")
+            return [item[1] for item in para] if detail == 0 else format_output(para, output_format, True, detail)
         if reformat:
             _, img_cv_grey = reformat_input(img_cv_grey)
         H, W = img_cv_grey.shape
         if horizontal_list is None and free_list is None:
             horizontal_list, free_list = [[0, W, 0, H]], []
-        return self.recognize_device(self._to_dev(img_cv_grey[None]), [horizontal_list or []], [free_list or []],
-                                     contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail, decoder=decoder,
-                                     beamWidth=beamWidth, rotation_info=rotation_info)[0]
+        res = self.recognize_device(self._to_dev(img_cv_grey[None]), [horizontal_list or []], [free_list or []],
+                                    contrast_ths=contrast_ths, adjust_contrast=adjust_contrast, detail=detail, decoder=decoder,
+                                    beamWidth=beamWidth, rotation_info=rotation_info, allowlist=allowlist, blocklist=blocklist)[0]
+        return format_output(res, output_format, False, detail)
 
     # -- stage-level entry points (tests, bench) --------------------------------------------
     def detect_dims(self, H, W, canvas_size=2560, mag_ratio=1.0):

@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--cpu-pages", type=int, default=16, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
     ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf",
                     help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf; '' = none)")
-    ap.add_argument("--leg-steps", type=int, default=4)
+    ap.add_argument("--leg-steps", type=int, default=6)
     ap.add_argument("--in-flight", type=int, default=2, help="calls in flight on the one Reader during the timed region (worker threads; bbocr_config::call_slots = 2)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 renders every rank's pages and scatters them (dist.scatter_pages: grouped "
@@ -532,7 +532,7 @@ def main():
             legs["single_page"] = leg_single_page(reader, uniq)
             log(f"leg single_page: p50 {legs['single_page']['p50_ms']:.2f} ms")
         if "host_pages" in names and args.config == "p1":
-            legs["host_pages"] = leg_host_pages(reader, uniq, B, args.leg_steps, pages / dt, args.in_flight)
+            legs["host_pages"] = leg_host_pages(reader, uniq, B, max(12, args.leg_steps), pages / dt, args.in_flight)
             log(f"leg host_pages: {legs['host_pages']['value']:.1f} images/s")
         if "lowconf" in names and args.rec_weights == "trained":
             legs["lowconf"] = leg_lowconf(reader, (cs, rs))

@@ -500,6 +500,12 @@ def test_paragraph_and_allowlist_modes(reader):
     assert len(para) >= 1 and all(len(p) == 2 for p in para)
     assert sorted(" ".join(p[1] for p in para).split()) == sorted(" ".join(r[1] for r in plain).split())
     assert reader.readtext(img, paragraph=True, detail=0) == [p[1] for p in para]
+    # Reader.recognize(paragraph=True) on the detector's own boxes: the same paragraphs (upstream applies get_paragraph inside recognize)
+    from bb_ocr_amd.reader import reformat_input
+    _, grey = reformat_input(img)
+    hl, fl = reader.detect(img)
+    assert reader.recognize(grey, hl[0], fl[0], paragraph=True, reformat=False) == para
+    assert reader.recognize(grey, hl[0], fl[0], paragraph=True, detail=0, reformat=False) == [p[1] for p in para]
     digits = reader.readtext(img, allowlist="0123456789")
     assert [d[0] for d in digits] == [r[0] for r in plain]                        # same boxes
     assert all(set(d[1]) <= set("0123456789") for d in digits) and any(d[1] for d in digits)
