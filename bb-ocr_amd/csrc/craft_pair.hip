@@ -42,44 +42,64 @@ inline int grid_for(size_t total, int cap = 16384) {
 // ------------------------------------------------------------------------------------------------ conv1_1 (3 -> 64) + BN + ReLU, fp32
 // uint8 RGB pages [N, Hi, Wi, 3] on the zero canvas H x W -> pair [N, H, W, 64 | 64].  normalizeMeanVariance in fp32 exactly as numpy does
 // it ((x - mean * 255) / (std * 255)); pixels of the canvas beyond the page are raw zeros (normalised like any pixel), pixels beyond the
-// canvas are the convolution's zero padding.  w: folded fp32 [64][3][3][3] (cout, cin, ky, kx), b: [64].  One thread = one pixel x 8 couts.
+// canvas are the convolution's zero padding.  w: folded fp32 [64][3][3][3] (cout, cin, ky, kx), b: [64].
+// One thread = one pixel x all 64 couts: its 27 normalised inputs live in registers, the weights are read from LDS as [27][64] -- every
+// lane of a wave reads the same address (a broadcast: no bank conflicts), 4 weights per ds_read_b128 -- and the 1,728 FMAs per pixel run at
+// the fp32 issue rate.  (The first version gave each thread 8 couts and read the weights from global memory inside the tap loop: 38 ms per
+// 11-page pass, a third of the exact mode's step; this one ~1 ms.)
 __global__ void __launch_bounds__(256) pair_conv1_1_kernel(const uint8_t* __restrict__ rgb, int N, int Hi, int Wi, int H, int W, const float* __restrict__ w,
                                                            const float* __restrict__ b, uint16_t* __restrict__ out) {
-    const size_t total = (size_t)N * H * W * 8;
+    __shared__ __attribute__((aligned(16))) float wl[27 * 64 + 64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int k = i >> 6, co = i & 63;                    // k = (ky * 3 + kx) * 3 + ch
+        const int tap = k / 3, ch = k - tap * 3;
+        wl[i] = w[((size_t)co * 3 + ch) * 9 + tap];
+    }
+    if (threadIdx.x < 64) wl[27 * 64 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
     const float mean[3] = {0.485f * 255.0f, 0.456f * 255.0f, 0.406f * 255.0f};
     const float sd[3] = {0.229f * 255.0f, 0.224f * 255.0f, 0.225f * 255.0f};
+    const size_t total = (size_t)N * H * W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i & 7);
-        size_t r = i >> 3;
-        const int x = (int)(r % W);
-        r /= W;
+        const int x = (int)(i % W);
+        const size_t r = i / W;
         const int y = (int)(r % H);
         const int n = (int)(r / H);
-        float acc[8];
+        float v[27];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = b[c8 * 8 + j];
         for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int iy = y - 1 + ky, ix = x - 1 + kx;
-                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;            // zero padding of the conv
-                const bool on_page = iy < Hi && ix < Wi;
+                const bool in_canvas = iy >= 0 && iy < H && ix >= 0 && ix < W;       // else: zero padding of the conv
+                const bool on_page = in_canvas && iy < Hi && ix < Wi;
                 const uint8_t* q = rgb + ((size_t)(n * Hi + (on_page ? iy : 0)) * Wi + (on_page ? ix : 0)) * 3;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float v = ((on_page ? (float)q[ch] : 0.f) - mean[ch]) / sd[ch];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[((size_t)(c8 * 8 + j) * 3 + ch) * 9 + ky * 3 + kx], v, acc[j]);
-                }
+                for (int ch = 0; ch < 3; ++ch) v[(ky * 3 + kx) * 3 + ch] = in_canvas ? ((on_page ? (float)q[ch] : 0.f) - mean[ch]) / sd[ch] : 0.f;
+            }
+        uint16_t* op = out + i * 128;
+#pragma unroll 1
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float acc[8];
+            {
+                const f32x4 b0 = *(const f32x4*)(wl + 27 * 64 + c8 * 8), b1 = *(const f32x4*)(wl + 27 * 64 + c8 * 8 + 4);
+                acc[0] = b0[0]; acc[1] = b0[1]; acc[2] = b0[2]; acc[3] = b0[3]; acc[4] = b1[0]; acc[5] = b1[1]; acc[6] = b1[2]; acc[7] = b1[3];
             }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
-        uint16_t* op = out + (i >> 3) * 128 + c8 * 8;
-        pair_store8(op, op + 64, acc);
+            for (int k = 0; k < 27; ++k) {
+                const f32x4 w0 = *(const f32x4*)(wl + k * 64 + c8 * 8), w1 = *(const f32x4*)(wl + k * 64 + c8 * 8 + 4);
+                acc[0] = fmaf(w0[0], v[k], acc[0]); acc[1] = fmaf(w0[1], v[k], acc[1]); acc[2] = fmaf(w0[2], v[k], acc[2]); acc[3] = fmaf(w0[3], v[k], acc[3]);
+                acc[4] = fmaf(w1[0], v[k], acc[4]); acc[5] = fmaf(w1[1], v[k], acc[5]); acc[6] = fmaf(w1[2], v[k], acc[6]); acc[7] = fmaf(w1[3], v[k], acc[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+            pair_store8(op + c8 * 8, op + 64 + c8 * 8, acc);
+        }
     }
 }
 hipError_t launch_pair_conv1_1(const uint8_t* rgb, int N, int Hi, int Wi, int H, int W, const float* w, const float* b, uint16_t* out, hipStream_t s) {
-    const size_t total = (size_t)N * H * W * 8;
-    hipLaunchKernelGGL(pair_conv1_1_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, s, rgb, N, Hi, Wi, H, W, w, b, out);
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL(pair_conv1_1_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, s, rgb, N, Hi, Wi, H, W, w, b, out);
     return hipGetLastError();
 }
 

@@ -57,7 +57,7 @@ CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, 
 TRAINED_CRNN = os.path.join(ROOT, "tests", "golden", "crnn_synth_fp16.npz")
 METRIC = {"p1": "book-page images/sec end-to-end (detect+recognize) @1280x960",
           "a4": "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)"}
-DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands in the recogniser)", "mixed": "bf16 (detector) + fp16 (recogniser)"}
+DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands, three MFMA product terms per layer, in both networks)", "mixed": "bf16 (detector) + fp16 (recogniser)"}
 
 
 def log(msg, rank=0):
