@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) 
         const int next = tile + gridDim.x;
         if constexpr (DB) {
             // every wave has finished reading buffer buf^1 (tile - gridDim.x): the next tile's patch may land there
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (next < ntiles) {
                 issue_patch(next, buf ^ 1);
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPB * NCH) : "memory");     // vmcnt retires in order: this tile's patch (and the weights) have landed
@@ -1199,7 +1199,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_resw_kernel(const ConvArgs a) 
         const int n = id / a.tiles_y;
         if constexpr (!DB) {
             // single patch buffer: everybody is done reading it, the next tile's patch travels while this tile's epilogue stores
-            asm volatile("s_barrier" ::: "memory");
+            // (lgkmcnt(0): the compiler may sink the last MFMAs and their LDS wait below a bare barrier -- see conv3x3_up4_kernel)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (next < ntiles) issue_patch(next, 0);
         }
         if constexpr (LEAN) conv_epilogue_pool2x2_lean<EL, MF>(a, acc, n, ty * 16, tx * 16, wm, lane);
@@ -1298,7 +1299,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
         const int y0 = (int)sy, x0 = (int)sx;
         const int y1 = y0 + (y0 < LH - 1 ? 1 : 0), x1 = x0 + (x0 < LW - 1 ? 1 : 0);
         const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-        const f32x2_t w00 = {hy * hx, hy * hx}, w01 = {hy * lx, hy * lx}, w10 = {ly * hx, ly * hx}, w11 = {ly * lx, ly * lx};
+        // The four blend weights are FINISHED here, before any load of this fragment is issued, and pinned in registers (conv_epilogue<ADDUP>
+        // computes its weights in issue() as well).  Left to itself hipcc sinks their computation into the `pp < NP` block below, i.e.
+        // directly behind the 16-MFMA chain, whose intermediate accumulators it renames (dst != srcC) and whose temporaries it then reuses
+        // for the weights: packed-fp32 VALU writes to registers that MFMAs still in flight read as srcC.  The hazard recogniser's wait
+        // states did not cover it (two waves share the matrix pipe, a dependent 8-pass MFMA starts late): thousands of u4b values per launch
+        // differed from the two-launch path, differently on every run.  Round 4, tools/micro/up4_check.hip: pinned 0 of 2.4 M values differ
+        // in 16 runs; unpinned 7,000-40,000 per run (also with nops or a full vmcnt wait around the chain).
+        float a00 = hy * hx, a01 = hy * lx, a10 = ly * hx, a11 = ly * lx;
+        asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11));
+        const f32x2_t w00 = {a00, a00}, w01 = {a01, a01}, w10 = {a10, a10}, w11 = {a11, a11};
         const uint16_t* zb = a.addup + (size_t)n * LH * LW * a.up_cs + g * 8;
         const uint16_t* z00 = zb + ((size_t)y0 * LW + x0) * a.up_cs;
         const uint16_t* z01 = zb + ((size_t)y0 * LW + x1) * a.up_cs;
@@ -1319,6 +1329,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = El<EL>::mfma(w1[c][j], sv[c], d[j]);
+
         if (G.pp < NP) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1392,7 +1403,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_up4_kernel(const ConvArgs a) {
                     for (int j = 0; j < NF; ++j) acc[f][j] = El<EL>::mfma(af[j], bq[f], acc[f][j]);
             }
         }
-        asm volatile("s_barrier" ::: "memory");          // everybody is done reading the patch: the next tile's phase A may overwrite it
+        // Everybody is done reading the patch: the next tile's phase A may overwrite it.  lgkmcnt(0) is PART of this barrier: the "memory"
+        // clobber keeps the ds_reads above it, but hipcc sinks the last MFMAs -- and with them the s_waitcnt of the last fragment read -- below
+        // the asm, so a wave could pass a bare s_barrier with a patch read still queued, a faster wave's phase-A ds_write of the NEXT tile could
+        // be served first, and one tap of one fragment row was then multiplied with the next tile's pixels: heat-maps that differed from run
+        // to run in ~1 % of the values on tiles after a workgroup's first (round 4: tools/determinism_probe.py, tools/micro/up4_check.hip).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         conv_epilogue<EL, MF>(a, acc, n, 0, oy0, ox0, wave, 0, 1, lane, 64);
     }
 }
@@ -1795,6 +1811,9 @@ static hipError_t launch_conv_el(const ConvPlan& p, ConvArgs a, hipStream_t s) {
         }
     }
     if (a.post_w) return hipErrorNotSupported;
+    // the generic kernel below knows neither the fused conv1_1 producer (in0 would be read as a 64-channel tensor: an out-of-bounds access on
+    // the uint8 page -- what BBOCR_CONV_DMA=0 did in a diagnostic build in round 4) nor the up-sampling epilogue: refuse, never run garbage
+    if (a.c11_w || a.addup) return hipErrorNotSupported;
     const int piter = cdiv(a.NP / 16, NWV);
     if (BN == 128) return piter <= 4 ? launch_cfg<EL, 2, 2, 8, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 2, 2, 8, 8>(a, grid, s) : launch_cfg<EL, 2, 2, 8, 16>(a, grid, s));
     if (BN == 64) return piter <= 4 ? launch_cfg<EL, 4, 1, 4, 4>(a, grid, s) : (piter <= 8 ? launch_cfg<EL, 4, 1, 4, 8>(a, grid, s) : launch_cfg<EL, 4, 1, 4, 16>(a, grid, s));
