@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle (torch fp32) with one thread per core of a 128+-core GPU host is slower than with 16 (17 s instead of 2.5 s per
+    # 1280x960 page on the round-4 box): keep it to this process's share, at most 16 -- what bench.py's cpu_baseline leg uses
+    try:
+        import torch
+
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except Exception:
+        pass
 
 
 def _has_gpu():
