@@ -341,6 +341,16 @@ inline HostPool& host_pool(bbocr_ctx* c) {
     return *c->pool;
 }
 
+// is another pipeline call running on this context right now (another call slot busy)?
+inline bool other_call_in_flight(bbocr_ctx* c) {
+    bbocr_ctx* root = c->root;
+    std::lock_guard<std::mutex> lk(root->pool_mu);
+    if (root != c && root->slot_busy) return true;
+    for (bbocr_ctx* s : root->slots)
+        if (s != c && s->slot_busy) return true;
+    return false;
+}
+
 // ---- call slots
 struct EnqLock {       // see bbocr_ctx::enq_mu; never held across a host wait for the device
     std::unique_lock<std::mutex> lk;

@@ -305,8 +305,10 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
     // Pages per detector pass.  Explicit det_sub_batch: uniform passes of that size.  Auto: passes as large as a 96 GB
     // activation arena allows (sized by a dry run on one page; at most 64 pages), and -- when the caller overlaps box
     // extraction with the next pass (readtext_batch) -- a short last pass of 8 pages (of 1280x960; fewer, larger ones by pixel count),
-    // because only the LAST pass's CCL + host geometry is exposed: 64 pages run as [56, 8], 16 A4@300dpi scans as [14, 2].
+    // because only the LAST pass's CCL + host geometry is exposed: 64 pages run as [56, 8], 16 A4@300dpi scans as [14, 2] -- when the call
+    // is alone on its context.
     std::vector<int> passes;
+    int sb_other = 0;
     if (c->cfg.det_sub_batch > 0) {
         for (int b0 = 0; b0 < B; b0 += c->cfg.det_sub_batch) passes.push_back(std::min(c->cfg.det_sub_batch, B - b0));
     } else {
@@ -318,12 +320,19 @@ void detect_impl(bbocr_ctx* c, const uint8_t* rgb, int B, int H, int W, const bb
         // pages larger than 1280x960 (an A4@300dpi canvas is 3.8 of them) count by their pixels: 16 A4 scans run as [14, 2]
         const double equiv = std::max(1.0, (double)d.th * d.tw / (960.0 * 1280.0));
         const int tail_pages = tail_knob > 0 ? std::max(1, (int)std::lround(tail_knob / equiv)) : 0;
-        const int tail = (after_sub && B * equiv >= 24.0 && cap > tail_pages && B > tail_pages && tail_pages > 0) ? tail_pages : 0;
+        // ... unless another call is in flight on this context (bbocr_config::call_slots): its kernels fill the card while this call's
+        // last pass is turned into boxes, so the short pass has nothing left to hide and only costs its own inefficiency (round 4, two calls
+        // in flight: [56, 8] 942, one pass of 64 959, [32, 32] 947 images/s)
+        const bool alone = !other_call_in_flight(c);
+        const int tail = (alone && after_sub && B * equiv >= 24.0 && cap > tail_pages && B > tail_pages && tail_pages > 0) ? tail_pages : 0;
         const int body = B - tail, nbig = cdiv(body, cap);
         for (int i = 0; i < nbig; ++i) passes.push_back(body / nbig + (i < body % nbig ? 1 : 0));
         if (tail) passes.push_back(tail);
+        sb_other = cdiv(B, cdiv(B, cap));     // largest pass of the schedule WITHOUT a tail (taken when another call is in flight)
     }
-    const int sb = *std::max_element(passes.begin(), passes.end());
+    // work buffers are sized for whichever of the two schedules has the larger pass: a context whose calls are sometimes alone and
+    // sometimes not must not re-allocate a 60-GB arena when the schedule flips
+    const int sb = std::max(sb_other, *std::max_element(passes.begin(), passes.end()));
     const bool need_resize = (d.th != H || d.tw != W);
     if (need_resize) c->resized.ensure((size_t)sb * d.th * d.tw * 3);
     c->arena.begin(true);
