@@ -570,6 +570,51 @@ def test_two_calls_in_flight_equal_the_serial_path(states):
     one.close()
 
 
+def test_mixed_entry_points_from_three_threads(states):
+    """Call slots under a mix of entry points: three threads hammer ONE Reader with different calls at once -- whole readtext on a batch,
+    detector only, boxes from a heat-map, recognise explicit boxes, a single page from an array, the pre-processing chain -- for a few
+    hundred calls; every result equals what the same call returned alone.  (Two slots, so the third thread always waits for one; a work
+    buffer shared between slots by mistake, a stream wait on the wrong event or an error string crossing threads would show.)"""
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+
+    import bb_ocr_amd
+    from bb_ocr_amd import preprocess as dev_pp
+    from bb_ocr_amd import synth
+
+    r = bb_ocr_amd.Reader(["en"], gpu=True, weights=states, precision="fp16")
+    pages = [synth.page(61_000 + i, width=640, height=384, lines=4 + i % 4, margin=24, colour=bool(i & 1))[0] for i in range(6)]
+    rgb = torch.from_numpy(np.stack(pages)).cuda()
+    gray = torch.from_numpy(np.stack([p[..., 1] for p in pages])).cuda()
+    heat, ratio = r.heatmap_device(rgb)
+    hori, free, _ = r.boxes_from_heatmap(heat, ratio)
+    bgr = torch.from_numpy(np.ascontiguousarray(pages[0][:, :, ::-1])).cuda()
+    jobs = {
+        "readtext_batch": lambda: r.readtext_device(rgb),
+        "detect": lambda: r.heatmap_device(rgb[:3])[0].cpu().numpy().tobytes(),
+        "boxes": lambda: r.boxes_from_heatmap(heat, ratio),
+        "recognize": lambda: r.recognize_device(gray, hori, free),
+        "single": lambda: r.readtext(pages[2]),
+        "beam": lambda: r.readtext(pages[3], decoder="beamsearch"),
+        "preprocess": lambda: dev_pp.preprocess_bgr_device(r, bgr).cpu().numpy().tobytes(),
+    }
+    want = {k: f() for k, f in jobs.items()}
+    assert want["readtext_batch"][2] == want["single"] and sum(len(p) for p in want["recognize"]) > 10
+    order = [k for k in jobs for _ in range(24)]
+    random.Random(7).shuffle(order)
+
+    def run(k):
+        return k, jobs[k]()
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for k, got in ex.map(run, order):
+            assert got == want[k], k
+    with pytest.raises(ValueError):                  # a failing call on one thread leaves the others' slots usable
+        r.readtext(np.zeros((4, 4), dtype=np.float32))
+    assert r.readtext_device(rgb) == want["readtext_batch"]
+    r.close()
+
+
 def test_context_teardown_returns_device_memory(states):
     """Ownership: the context owns weights, work buffers, streams; close() gives all of it back.  Three create / use / close
     cycles (every optional buffer exercised: beam-search probabilities, rotation variants, the pre-processing planes) leave the free
