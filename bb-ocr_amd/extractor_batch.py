@@ -124,12 +124,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
         finally:
             batches.put(None)
 
-    worker = threading.Thread(target=assemble, daemon=True)
-    worker.start()
-    while True:
-        item = batches.get()
-        if item is None:
-            break
+    def ocr(item):
         ids, rgb, gray = item
         try:
             res = reader.readtext_arrays(rgb, gray, **readtext_kw)
@@ -143,5 +138,24 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
                     res.append([])
         for i, r in zip(ids, res):
             texts[i] = " ".join(t[1] for t in r)
+
+    worker = threading.Thread(target=assemble, daemon=True)
+    worker.start()
+    # two device batches in flight on the one Reader (bbocr_config::call_slots, the reference's own ThreadPoolExecutor contract,
+    # batch_processor_enhanced.py:215): the H2D copy and detector of batch k+1 run while batch k's host thread finishes its boxes and strings
+    in_flight = threading.Semaphore(2)
+    with ThreadPoolExecutor(max_workers=2, thread_name_prefix="bbocr-ocr") as device_pool:
+        futs = []
+        while True:
+            item = batches.get()
+            if item is None:
+                break
+            in_flight.acquire()
+            fut = device_pool.submit(ocr, item)
+            fut.add_done_callback(lambda _f: in_flight.release())
+            futs.append(fut)
+            del item
+        for fut in futs:
+            fut.result()
     worker.join()
     return texts

@@ -570,6 +570,19 @@ def test_two_calls_in_flight_equal_the_serial_path(states):
     one.close()
 
 
+def test_readtext_batched_streams_large_groups(reader, monkeypatch):
+    """Reader.readtext_batched splits a shape group larger than BBOCR_MAX_DEVICE_BATCH into device batches and streams them with two calls in
+    flight (readtext_stream): same results, same order, as one device batch -- mixed shapes included."""
+    from bb_ocr_amd import synth
+
+    imgs = [synth.page(72_000 + i, width=512 if i % 3 else 448, height=320, lines=3 + i % 4, margin=20)[0] for i in range(11)]
+    want = reader.readtext_batched(imgs)
+    assert any(want) and want[0] == reader.readtext(imgs[0])
+    monkeypatch.setenv("BBOCR_MAX_DEVICE_BATCH", "3")
+    assert reader.readtext_batched(imgs) == want
+    assert reader.readtext_batched(imgs, detail=0) == [[t for _, t, _ in page] for page in want]
+
+
 def test_mixed_entry_points_from_three_threads(states):
     """Call slots under a mix of entry points: three threads hammer ONE Reader with different calls at once -- whole readtext on a batch,
     detector only, boxes from a heat-map, recognise explicit boxes, a single page from an array, the pre-processing chain -- for a few
