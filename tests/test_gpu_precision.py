@@ -387,6 +387,23 @@ def test_detector_heatmaps_are_bit_reproducible():
                 assert np.array_equal(first, r.heatmap_device(rgb)[0].cpu().numpy()), (prec, pages.shape, "after other work")
                 single = np.concatenate([r.heatmap_device(rgb[i:i + 1])[0].cpu().numpy() for i in range(len(pages))])
                 assert np.array_equal(first, single), (prec, pages.shape, "page by page")
+            # ... and with two calls in flight on the context (two call slots, sequence stages on their own streams)
+            if prec != "exact":
+                from concurrent.futures import ThreadPoolExecutor
+
+                tb, ts = torch.from_numpy(big).cuda(), torch.from_numpy(small).cuda()
+                wb, ws = r.heatmap_device(tb)[0].cpu().numpy(), r.heatmap_device(ts)[0].cpu().numpy()
+                full = r.readtext_device(tb)
+
+                def job(k):
+                    if k % 3 == 0:
+                        return np.array_equal(wb, r.heatmap_device(tb)[0].cpu().numpy())
+                    if k % 3 == 1:
+                        return np.array_equal(ws, r.heatmap_device(ts)[0].cpu().numpy())
+                    return r.readtext_device(tb) == full
+
+                with ThreadPoolExecutor(max_workers=2) as ex:
+                    assert all(ex.map(job, range(18))), (prec, "two calls in flight")
             # the recogniser network alone: logits of 40 random crops, call to call
             g = torch.Generator().manual_seed(5)
             x = torch.rand(40, 64, 512, generator=g) * 2 - 1
