@@ -11,46 +11,32 @@ int bbocr_op_preprocess_stage(bbocr_ctx* ctx, int stage, const uint8_t* dev_src,
         if (stage == 0) {
             pp_resize(ctx, dev_src, H, W, dev_dst, dh, dw);
         } else if (stage == 1) {
-            (void)pp_gauss(ctx, dev_src, H, W, dev_dst, param);
+            pp_gauss(ctx, dev_src, H, W, dev_dst, param);
         } else if (stage == 2 || stage == 3) {
             // pointwise PIL enhancers: the chain folds them into CLAHE's input LUT; stand-alone they are one lookup pass
-            uint8_t lut[256];
             if (stage == 2) {
                 ctx->pp_a.ensure(n);
-                ctx->pp_tab.ensure(512);
-                HIPCHK(hipMemsetAsync(ctx->pp_tab.p, 0, 8, ctx->stream));
                 // mean of the input: the 3x3 smoothing kernel with taps (0, 256, 0) is the identity and sums its output
-                HIPCHK(launch_pp_gauss3(dev_src, H, W, (uint8_t*)ctx->pp_a.p, 0, 256, 0, (unsigned long long*)ctx->pp_tab.p, ctx->stream));
-                unsigned long long sm = 0;
-                HIPCHK(hipMemcpyAsync(&sm, ctx->pp_tab.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-                slot_sync(ctx, ctx->stream);
-                pil_blend_lut((int)((double)sm / (double)n + 0.5), (float)param, lut);
-            } else {
-                pil_blend_lut(0, (float)param, lut);
+                pp_gauss(ctx, dev_src, H, W, (uint8_t*)ctx->pp_a.p, 0.0);
             }
-            ctx->pp_tab.ensure(512);
-            HIPCHK(hipMemcpyAsync((unsigned char*)ctx->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(launch_pp_lut(dev_src, dev_dst, (const uint8_t*)ctx->pp_tab.p + 256, n, ctx->stream));
-            slot_sync(ctx, ctx->stream);
+            HIPCHK(launch_pp_lut(dev_src, dev_dst, pp_fold_lut(ctx, n, stage == 2 ? param : 0.0, stage == 3 ? param : 0.0), n, ctx->stream));
         } else if (stage == 4) {
-            pp_clahe(ctx, dev_src, H, W, nullptr, dev_dst, param);
+            pp_clahe(ctx, dev_src, H, W, pp_fold_lut(ctx, n, 0.0, 0.0), dev_dst, param);
         } else if (stage == 5) {
             ctx->pp_b.ensure(n);
             ctx->pp_c.ensure(n);
             pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, (float)param, 30, 3);
-            slot_sync(ctx, ctx->stream);
         } else if (stage == 7) {
             ctx->pp_b.ensure(n);
             ctx->pp_c.ensure(n);
             pp_unsharp(ctx, dev_src, H, W, dev_dst, (uint8_t*)ctx->pp_b.p, (uint8_t*)ctx->pp_c.p, 1.0f, (int)param, 3);
-            slot_sync(ctx, ctx->stream);
         } else if (stage == 6) {
             // cv2.cvtColor(BGR2GRAY) on an interleaved 3-channel plane [H,W,3] (the gray plane reformat_input derives from arrays)
             HIPCHK(launch_gray(dev_src, dev_dst, n, ctx->stream));
-            slot_sync(ctx, ctx->stream);
         } else {
             fail(BBOCR_ERR_ARG, "unknown pre-processing stage");
         }
+        slot_sync(ctx, ctx->stream);                            // every stage only enqueues
     });
 }
 

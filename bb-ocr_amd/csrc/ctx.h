@@ -157,6 +157,9 @@ struct bbocr_ctx : WeightView {
     bool slot_busy = false;                   // this slot is running a call
     hipStream_t stream = nullptr;             // the compute stream (root's; slots share it: kernels of concurrent calls run in issue order)
     DevBuf pp_gray, pp_a, pp_b, pp_c, pp_tab;  // pre-processing chain (f2): planes and small tables
+    DevBuf pp_cubic;                           // cubic-resize weight tables, kept on the device while (W, dw, H, dh) repeats
+    int pp_cubic_key[4] = {0, 0, 0, 0};
+    unsigned long long pp_cubic_K[2] = {0, 0};
     unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
     int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
     hipStream_t cur = nullptr;                // stream the layer helpers launch on
@@ -325,10 +328,10 @@ double percentile_u8(const unsigned int* hist, size_t n, double q);
 void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, RecEarly& e);
 void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, std::vector<BoxJob>& jobs, std::vector<int>& box_off, RecEarly* early = nullptr);
 bbocr_result* export_result(int B, const std::vector<BoxJob>& jobs, const std::vector<int>& box_off);
-void pil_blend_lut(int in1, float alpha, uint8_t lut[256]);
-void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw);
-unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma);
-void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit);
+void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw);   // enqueues; the caller waits
+void pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma);
+const uint8_t* pp_fold_lut(bbocr_ctx* c, size_t n, double contrast, double brightness);
+void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* d_lut, uint8_t* dst, double clip_limit);
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent, int threshold);
 void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const bbocr_preproc_params& q, uint8_t* out, int dh, int dw);
 

@@ -172,5 +172,10 @@ hipError_t launch_pp_clahe_hist(const uint8_t* src, int H, int W, const uint8_t*
 hipError_t launch_pp_clahe_apply(const uint8_t* src, int H, int W, const uint8_t* lut, const uint8_t* tile_luts, int tw, int th, int tx, int ty,
                                  uint8_t* dst, hipStream_t s);
 hipError_t launch_pp_box_pass(const uint8_t* src, uint8_t* dst, int H, int W, int vertical, int r, unsigned int ww, unsigned int fw, hipStream_t s);
+hipError_t launch_pp_fold_lut(const unsigned long long* sum, unsigned long long n, float contrast, float brightness, uint8_t* lut, hipStream_t s);
+hipError_t launch_pp_clahe_luts(const unsigned int* hist, int tiles, int clip, float lut_scale, uint8_t* tile_luts, hipStream_t s);
 hipError_t launch_pp_lut(const uint8_t* src, uint8_t* dst, const uint8_t* lut, size_t total, hipStream_t s);
+bool pp_unsharp_fused_ok(int H, int W, int r, const uint8_t* a, const uint8_t* b, const uint8_t* c);
+hipError_t launch_pp_unsharp_fused(const uint8_t* in, uint8_t* tmp, uint8_t* dst, int H, int W, unsigned int ww, unsigned int fw, int percent,
+                                   int threshold, hipStream_t s);
 hipError_t launch_pp_unsharp(const uint8_t* in, const uint8_t* blur, uint8_t* dst, size_t total, int percent, int threshold, hipStream_t s);

@@ -2,7 +2,9 @@
 #include "ctx.h"
 
 // ------------------------------------------------------------------------------------------------ pre-processing chain (f2)
-// Host-side constants of the chain, computed exactly like oracle/preprocess.py (float32 where the C sources use float).
+// Host-side constants of the chain, computed exactly like oracle/preprocess.py (float32 where the C sources use float).  Every step only
+// ENQUEUES on the slot's stream: the data-dependent tables (enhancer LUT from the plane's mean, CLAHE tile LUTs from the tile histograms)
+// are computed by device kernels, so one page costs one wait at the end of the chain instead of one per step.
 // cv2.resize INTER_CUBIC through IPP (see preproc.hip::pp_resize_cubic_kernel and oracle/preprocess.py::_cubic_axis_exact): phase
 // t = n / (2 dst) exactly, weights as exact integers over K = 4 (2 dst)^3 and as correctly rounded doubles (both < 2^53)
 struct CubicAxis { std::vector<int> first; std::vector<double> wf; std::vector<long long> wi; unsigned long long K; };
@@ -42,13 +44,6 @@ void gaussian_taps3(double sigma, int k[3]) {   // getGaussianKernelBitExact -> 
         k[i] = r;
     }
 }
-void pil_blend_lut(int in1, float alpha, uint8_t lut[256]) {   // libImaging/Blend.c with a constant first image
-    for (int v = 0; v < 256; ++v) {
-        const float t = (float)in1 + alpha * (float)(v - in1);
-        if (alpha >= 0.f && alpha <= 1.f) lut[v] = (uint8_t)t;
-        else lut[v] = t <= 0.f ? 0 : (t >= 255.f ? 255 : (uint8_t)t);
-    }
-}
 static float pil_box_radius(float radius, int passes) {   // libImaging/BoxBlur.c::_gaussian_blur_radius
     const float sigma2 = radius * radius / (float)passes;
     const float L = (float)std::sqrt(12.0 * (double)sigma2 + 1.0);
@@ -58,41 +53,67 @@ static float pil_box_radius(float radius, int passes) {   // libImaging/BoxBlur.
     return l + a;
 }
 
+// Small device tables of the chain, at fixed offsets of pp_tab (every step of a chain is enqueued without a host round trip, so
+// no two steps may share an offset): pixel sum | folded enhancer LUT | 64 tile histograms | 64 tile LUTs
+enum : size_t { PP_SUM = 0, PP_LUT = 256, PP_HIST = 512, PP_TLUT = PP_HIST + 64 * 256 * 4, PP_TAB_BYTES = PP_TLUT + 64 * 256 };
+static unsigned char* pp_tab(bbocr_ctx* c) {
+    c->pp_tab.ensure(PP_TAB_BYTES);
+    return (unsigned char*)c->pp_tab.p;
+}
+
+// Enqueues the resize; the weight tables stay on the device while the geometry repeats (one page size per batch is the rule), so
+// only a change of (W, dw, H, dh) costs their computation, six uploads and a wait.
 void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw) {
-    const CubicAxis ax = cubic_axis(dw, W), ay = cubic_axis(dh, H);
     const size_t nx = (size_t)dw, ny = (size_t)dh;
-    const size_t bytes = (nx + ny) * (4 * 8 + 4 * 8) + (nx + ny) * 4 + 64;
-    c->pp_tab.ensure(bytes);
-    unsigned char* t = (unsigned char*)c->pp_tab.p;       // 8-byte tables first (alignment), then the int tables
+    const int key[4] = {W, dw, H, dh};
+    const bool hit = c->pp_cubic.p && std::memcmp(key, c->pp_cubic_key, sizeof key) == 0;
+    if (!hit) {
+        const size_t bytes = (nx + ny) * (4 * 8 + 4 * 8) + (nx + ny) * 4 + 64;
+        c->pp_cubic_key[1] = 0;                            // invalid until the uploads below have landed
+        slot_sync(c, c->stream);                           // an earlier resize may still read the tables about to be replaced
+        c->pp_cubic.ensure(bytes);
+    }
+    unsigned char* t = (unsigned char*)c->pp_cubic.p;     // 8-byte tables first (alignment), then the int tables
     double* wx = (double*)t;        t += nx * 32;
     double* wy = (double*)t;        t += ny * 32;
     long long* ix = (long long*)t;  t += nx * 32;
     long long* iy = (long long*)t;  t += ny * 32;
     int* x0 = (int*)t;              t += nx * 4;
     int* y0 = (int*)t;
-    HIPCHK(hipMemcpyAsync(wx, ax.wf.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(wy, ay.wf.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(ix, ax.wi.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(iy, ay.wi.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(x0, ax.first.data(), nx * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(y0, ay.first.data(), ny * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, ax.K, ay.K, c->stream));
-    slot_sync(c, c->stream);   // the host tables must outlive the copies
+    if (!hit) {
+        const CubicAxis ax = cubic_axis(dw, W), ay = cubic_axis(dh, H);
+        HIPCHK(hipMemcpyAsync(wx, ax.wf.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(wy, ay.wf.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(ix, ax.wi.data(), nx * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(iy, ay.wi.data(), ny * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(x0, ax.first.data(), nx * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(y0, ay.first.data(), ny * 4, hipMemcpyHostToDevice, c->stream));
+        slot_sync(c, c->stream);                           // the host tables must outlive the copies
+        c->pp_cubic_K[0] = ax.K;
+        c->pp_cubic_K[1] = ay.K;
+        std::memcpy(c->pp_cubic_key, key, sizeof key);
+    }
+    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, c->pp_cubic_K[0], c->pp_cubic_K[1], c->stream));
 }
-// GaussianBlur 3x3; returns the sum of the output pixels (for the following Contrast step)
-unsigned long long pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma) {
-    int k[3];
-    gaussian_taps3(sigma, k);
-    c->pp_tab.ensure(64);
-    HIPCHK(hipMemsetAsync(c->pp_tab.p, 0, 8, c->stream));
-    HIPCHK(launch_pp_gauss3(src, H, W, dst, k[0], k[1], k[2], (unsigned long long*)c->pp_tab.p, c->stream));
-    unsigned long long sum = 0;
-    HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
-    slot_sync(c, c->stream);
-    return sum;
+// GaussianBlur 3x3 (sigma <= 0: the identity taps); leaves the sum of the output pixels at PP_SUM for the following Contrast step.  Enqueues.
+void pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma) {
+    int k[3] = {0, 256, 0};
+    if (sigma > 0) gaussian_taps3(sigma, k);
+    unsigned char* t = pp_tab(c);
+    HIPCHK(hipMemsetAsync(t + PP_SUM, 0, 8, c->stream));
+    HIPCHK(launch_pp_gauss3(src, H, W, dst, k[0], k[1], k[2], (unsigned long long*)(t + PP_SUM), c->stream));
 }
-// CLAHE of lut[src] (lut = pointwise steps folded in front of it; identity if null)
-void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut_host, uint8_t* dst, double clip_limit) {
+// The two PIL enhancers as one LUT at PP_LUT, computed on the device from the sum at PP_SUM (a factor <= 0 skips its step; both <= 0
+// give the identity).  Enqueues.
+const uint8_t* pp_fold_lut(bbocr_ctx* c, size_t n, double contrast, double brightness) {
+    unsigned char* t = pp_tab(c);
+    HIPCHK(launch_pp_fold_lut((const unsigned long long*)(t + PP_SUM), (unsigned long long)n, (float)contrast, (float)brightness, t + PP_LUT,
+                              c->stream));
+    return t + PP_LUT;
+}
+// CLAHE of lut[src] (lut: device table from pp_fold_lut).  Histograms, clip / redistribute / cumulative LUTs and the interpolated
+// lookup are three launches on the stream, nothing comes back to the host.  Enqueues.
+void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* d_lut, uint8_t* dst, double clip_limit) {
     const int tx = 8, ty = 8;
     // clahe.cpp pads BOTH axes by tiles - (size % tiles) as soon as ONE of them is not a multiple of the grid -- a whole extra
     // 8 rows / columns on the axis that did divide (upstream quirk, restated as is)
@@ -100,48 +121,17 @@ void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* lut
     const int EH = pad ? H + (ty - H % ty) : H, EW = pad ? W + (tx - W % tx) : W;
     if (EH - H >= H || EW - W >= W) fail(BBOCR_ERR_ARG, "image smaller than the CLAHE tile grid");
     const int th = EH / ty, tw = EW / tx;
-    c->pp_tab.ensure(256 + (size_t)tx * ty * 256 * 4 + (size_t)tx * ty * 256);
-    uint8_t* d_lut = (uint8_t*)c->pp_tab.p;
-    unsigned int* d_hist = (unsigned int*)((unsigned char*)c->pp_tab.p + 256);
-    uint8_t* d_tl = (uint8_t*)c->pp_tab.p + 256 + (size_t)tx * ty * 256 * 4;
-    uint8_t ident[256];
-    for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
-    HIPCHK(hipMemcpyAsync(d_lut, lut_host ? lut_host : ident, 256, hipMemcpyHostToDevice, c->stream));
+    unsigned char* t = pp_tab(c);
+    unsigned int* d_hist = (unsigned int*)(t + PP_HIST);
+    uint8_t* d_tl = t + PP_TLUT;
     HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)tx * ty * 256 * 4, c->stream));
     HIPCHK(launch_pp_clahe_hist(src, H, W, d_lut, tw, th, tx, ty, d_hist, c->stream));
-    std::vector<unsigned int> hist((size_t)tx * ty * 256);
-    HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    slot_sync(c, c->stream);
-    // imgproc clahe.cpp: clip + redistribute, LUT = cvRound(cumsum * 255 / tile_area) in float
     const int area = th * tw;
     const float lut_scale = 255.0f / (float)area;
     int clip = 0;
     if (clip_limit > 0) clip = std::max((int)(clip_limit * area / 256), 1);
-    std::vector<uint8_t> tl((size_t)tx * ty * 256);
-    for (int t = 0; t < tx * ty; ++t) {
-        long long h[256];
-        for (int i = 0; i < 256; ++i) h[i] = hist[(size_t)t * 256 + i];
-        if (clip > 0) {
-            long long clipped = 0;
-            for (int i = 0; i < 256; ++i) if (h[i] > clip) { clipped += h[i] - clip; h[i] = clip; }
-            const long long batch = clipped / 256;
-            long long residual = clipped - batch * 256;
-            for (int i = 0; i < 256; ++i) h[i] += batch;
-            if (residual) {
-                const int step = std::max((int)(256 / residual), 1);
-                for (int i = 0; i < 256 && residual > 0; i += step, --residual) h[i] += 1;
-            }
-        }
-        long long sum = 0;
-        for (int i = 0; i < 256; ++i) {
-            sum += h[i];
-            const long v = std::lrintf((float)sum * lut_scale);
-            tl[(size_t)t * 256 + i] = (uint8_t)std::max<long>(0, std::min<long>(255, v));
-        }
-    }
-    HIPCHK(hipMemcpyAsync(d_tl, tl.data(), tl.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_pp_clahe_luts(d_hist, tx * ty, clip, lut_scale, d_tl, c->stream));
     HIPCHK(launch_pp_clahe_apply(src, H, W, d_lut, d_tl, tw, th, tx, ty, dst, c->stream));
-    slot_sync(c, c->stream);
 }
 // PIL UnsharpMask on src -> dst; tmp1/tmp2: two scratch planes of the same size
 void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, uint8_t* tmp1, uint8_t* tmp2, float radius, int percent,
@@ -150,6 +140,10 @@ void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, ui
     const int r = (int)fr;
     const unsigned int ww = (unsigned int)((float)(1 << 24) / (fr * 2.f + 1.f));
     const unsigned int fw = ((1u << 24) - (unsigned int)(r * 2 + 1) * ww) / 2;
+    if (pp_unsharp_fused_ok(H, W, r, src, tmp1, dst)) {       // the chain's own case (radius 1 -> box radius 0): 2 launches instead of 7
+        HIPCHK(launch_pp_unsharp_fused(src, tmp1, dst, H, W, ww, fw, percent, threshold, c->stream));
+        return;
+    }
     const uint8_t* cur = src;
     uint8_t* bufs[2] = {tmp1, tmp2};
     int w = 0;
@@ -178,49 +172,27 @@ void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const
         cur = d;
     }
     // the mean ImageEnhance.Contrast needs: the blur kernel sums its own output; without a blur stage the identity taps (0, 256, 0) do
-    unsigned long long sum = 0;
     bool have_sum = false;
     if (q.blur_sigma > 0) {
         uint8_t* d = next();
-        sum = pp_gauss(c, cur, dh, dw, d, q.blur_sigma);
+        pp_gauss(c, cur, dh, dw, d, q.blur_sigma);
         have_sum = true;
         cur = d;
     }
+    if (q.contrast > 0 && !have_sum) {
+        uint8_t* d = next();
+        pp_gauss(c, cur, dh, dw, d, 0.0);
+        cur = d;
+    }
     // the two PIL enhancers are pointwise: folded into one LUT, applied in front of CLAHE (or on their own when CLAHE is skipped)
-    uint8_t lut[256];
-    for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i;
-    bool have_lut = false;
-    if (q.contrast > 0) {
-        if (!have_sum) {
-            c->pp_tab.ensure(64);
-            HIPCHK(hipMemsetAsync(c->pp_tab.p, 0, 8, c->stream));
-            uint8_t* d = next();
-            HIPCHK(launch_pp_gauss3(cur, dh, dw, d, 0, 256, 0, (unsigned long long*)c->pp_tab.p, c->stream));
-            HIPCHK(hipMemcpyAsync(&sum, c->pp_tab.p, 8, hipMemcpyDeviceToHost, c->stream));
-            slot_sync(c, c->stream);
-            cur = d;
-        }
-        uint8_t l1[256];
-        pil_blend_lut((int)((double)sum / (double)n + 0.5), (float)q.contrast, l1);
-        for (int i = 0; i < 256; ++i) lut[i] = l1[lut[i]];
-        have_lut = true;
-    }
-    if (q.brightness > 0) {
-        uint8_t l2[256];
-        pil_blend_lut(0, (float)q.brightness, l2);
-        for (int i = 0; i < 256; ++i) lut[i] = l2[lut[i]];
-        have_lut = true;
-    }
+    const bool have_lut = q.contrast > 0 || q.brightness > 0;
     if (q.clahe_clip > 0) {
         uint8_t* d = next();
-        pp_clahe(c, cur, dh, dw, have_lut ? lut : nullptr, d, q.clahe_clip);
+        pp_clahe(c, cur, dh, dw, pp_fold_lut(c, n, q.contrast, q.brightness), d, q.clahe_clip);
         cur = d;
     } else if (have_lut) {
         uint8_t* d = next();
-        c->pp_tab.ensure(512);
-        HIPCHK(hipMemcpyAsync((unsigned char*)c->pp_tab.p + 256, lut, 256, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(launch_pp_lut(cur, d, (const uint8_t*)c->pp_tab.p + 256, n, c->stream));
-        slot_sync(c, c->stream);
+        HIPCHK(launch_pp_lut(cur, d, pp_fold_lut(c, n, q.contrast, q.brightness), n, c->stream));
         cur = d;
     }
     if (q.unsharp_percent > 0 && q.unsharp_radius > 0) {

@@ -215,6 +215,22 @@ def test_preprocess_chain_bit_exact_vs_oracle(reader):
         assert np.array_equal(stage(0, ties, 0, int(shape[0] * 1.5), 180), pp.resize_cubic_u8(ties, 180, int(shape[0] * 1.5)))
         odd = rng.integers(0, 256, (shape[0], 97), dtype=np.uint8)                 # a size ratio that is not 3/2: general rational phases
         assert np.array_equal(stage(0, odd, 0, shape[0] + 13, 131), pp.resize_cubic_u8(odd, 131, shape[0] + 13))
+        # downscales: 0.7x stays on the LDS-tiled kernel (larger source windows), 0.3x exceeds its window and takes the per-pixel kernel
+        for f in (0.7, 0.3):
+            sh_, sw_ = max(int(shape[0] * f), 8), max(int(shape[1] * f), 8)
+            assert np.array_equal(stage(0, a, 0, sh_, sw_), pp.resize_cubic_u8(a, sw_, sh_)), (shape, f)
+    # planes on the dword kernels (W % 4 == 0) whose sizes are NOT multiples of the CLAHE grid / of the resize and blur tiles, a narrow one
+    # (W = 8: every thread of the fused row passes is both the first and the last of its row) and one shorter than a column strip
+    for shape in ((250, 332), (403, 260), (37, 8), (9, 64), (522, 1028)):
+        img = rng.normal(150, 60, shape).clip(0, 255).astype(np.uint8)
+        if shape[1] >= 64:
+            assert np.array_equal(stage(4, img, 2.5), pp.clahe_u8(img, 2.5, (8, 8))), shape
+            assert np.array_equal(stage(4, img, 40.0), pp.clahe_u8(img, 40.0, (8, 8))), shape
+            dh, dw = int(shape[0] * 1.5), int(shape[1] * 1.5)
+            assert np.array_equal(stage(0, img, 0, dh, dw), pp.resize_cubic_u8(img, dw, dh)), shape
+        assert np.array_equal(stage(5, img, 1.0), pp.pil_unsharp_L(img, 1.0, 30, 3)), shape
+        assert np.array_equal(stage(7, img, 60), pp.pil_unsharp_L(img, 1.0, 60, 3)), shape
+        assert np.array_equal(stage(5, img, 2.0), pp.pil_unsharp_L(img, 2.0, 30, 3)), shape        # box radius > 0: the per-pass kernels
     # the whole chain on a rendered page (BGR) and on noise
     page = synth.page(77, width=640, height=400, lines=8, margin=24)[0][:, :, ::-1]
     for bgr in (np.ascontiguousarray(page), rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)):
