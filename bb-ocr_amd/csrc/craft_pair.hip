@@ -46,7 +46,7 @@ inline int grid_for(size_t total, int cap = 16384) {
 // One thread = one pixel x all 64 couts: its 27 normalised inputs live in registers, the weights are read from LDS as [27][64] -- every
 // lane of a wave reads the same address (a broadcast: no bank conflicts), 4 weights per ds_read_b128 -- and the 1,728 FMAs per pixel run at
 // the fp32 issue rate.  (The first version gave each thread 8 couts and read the weights from global memory inside the tap loop: 38 ms per
-// 11-page pass, a third of the exact mode's step; this one ~1 ms.)
+// 11-page pass, a third of the exact mode's step; this one ~1 ms.)  The pair leaves through an LDS stage as contiguous lines (below).
 __global__ void __launch_bounds__(256) pair_conv1_1_kernel(const uint8_t* __restrict__ rgb, int N, int Hi, int Wi, int H, int W, const float* __restrict__ w,
                                                            const float* __restrict__ b, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float wl[27 * 64 + 64];
@@ -59,42 +59,55 @@ __global__ void __launch_bounds__(256) pair_conv1_1_kernel(const uint8_t* __rest
     __syncthreads();
     const float mean[3] = {0.485f * 255.0f, 0.456f * 255.0f, 0.406f * 255.0f};
     const float sd[3] = {0.229f * 255.0f, 0.224f * 255.0f, 0.225f * 255.0f};
+    // a pixel's 256 output bytes ([hi 64 | lo 64]) are staged in LDS (row pitch 272 B: the lanes' 16-byte pieces fall on different
+    // banks) and leave as one contiguous 64-KB block per 256 pixels, 16 B per lane: written straight from the registers every store
+    // instruction touched 64 different 256-byte segments, and the kernel ran at a third of the rate its stores allow
+    __shared__ __attribute__((aligned(16))) unsigned char stage[256 * 272];
     const size_t total = (size_t)N * H * W;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % W);
-        const size_t r = i / W;
-        const int y = (int)(r % H);
-        const int n = (int)(r / H);
-        float v[27];
+    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + threadIdx.x;
+        if (i < total) {
+            const int x = (int)(i % W);
+            const size_t r = i / W;
+            const int y = (int)(r % H);
+            const int n = (int)(r / H);
+            float v[27];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = y - 1 + ky, ix = x - 1 + kx;
-                const bool in_canvas = iy >= 0 && iy < H && ix >= 0 && ix < W;       // else: zero padding of the conv
-                const bool on_page = in_canvas && iy < Hi && ix < Wi;
-                const uint8_t* q = rgb + ((size_t)(n * Hi + (on_page ? iy : 0)) * Wi + (on_page ? ix : 0)) * 3;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = y - 1 + ky, ix = x - 1 + kx;
+                    const bool in_canvas = iy >= 0 && iy < H && ix >= 0 && ix < W;       // else: zero padding of the conv
+                    const bool on_page = in_canvas && iy < Hi && ix < Wi;
+                    const uint8_t* q = rgb + ((size_t)(n * Hi + (on_page ? iy : 0)) * Wi + (on_page ? ix : 0)) * 3;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) v[(ky * 3 + kx) * 3 + ch] = in_canvas ? ((on_page ? (float)q[ch] : 0.f) - mean[ch]) / sd[ch] : 0.f;
-            }
-        uint16_t* op = out + i * 128;
+                    for (int ch = 0; ch < 3; ++ch) v[(ky * 3 + kx) * 3 + ch] = in_canvas ? ((on_page ? (float)q[ch] : 0.f) - mean[ch]) / sd[ch] : 0.f;
+                }
+            uint16_t* op = (uint16_t*)(stage + threadIdx.x * 272);
 #pragma unroll 1
-        for (int c8 = 0; c8 < 8; ++c8) {
-            float acc[8];
-            {
-                const f32x4 b0 = *(const f32x4*)(wl + 27 * 64 + c8 * 8), b1 = *(const f32x4*)(wl + 27 * 64 + c8 * 8 + 4);
-                acc[0] = b0[0]; acc[1] = b0[1]; acc[2] = b0[2]; acc[3] = b0[3]; acc[4] = b1[0]; acc[5] = b1[1]; acc[6] = b1[2]; acc[7] = b1[3];
-            }
+            for (int c8 = 0; c8 < 8; ++c8) {
+                float acc[8];
+                {
+                    const f32x4 b0 = *(const f32x4*)(wl + 27 * 64 + c8 * 8), b1 = *(const f32x4*)(wl + 27 * 64 + c8 * 8 + 4);
+                    acc[0] = b0[0]; acc[1] = b0[1]; acc[2] = b0[2]; acc[3] = b0[3]; acc[4] = b1[0]; acc[5] = b1[1]; acc[6] = b1[2]; acc[7] = b1[3];
+                }
 #pragma unroll
-            for (int k = 0; k < 27; ++k) {
-                const f32x4 w0 = *(const f32x4*)(wl + k * 64 + c8 * 8), w1 = *(const f32x4*)(wl + k * 64 + c8 * 8 + 4);
-                acc[0] = fmaf(w0[0], v[k], acc[0]); acc[1] = fmaf(w0[1], v[k], acc[1]); acc[2] = fmaf(w0[2], v[k], acc[2]); acc[3] = fmaf(w0[3], v[k], acc[3]);
-                acc[4] = fmaf(w1[0], v[k], acc[4]); acc[5] = fmaf(w1[1], v[k], acc[5]); acc[6] = fmaf(w1[2], v[k], acc[6]); acc[7] = fmaf(w1[3], v[k], acc[7]);
-            }
+                for (int k = 0; k < 27; ++k) {
+                    const f32x4 w0 = *(const f32x4*)(wl + k * 64 + c8 * 8), w1 = *(const f32x4*)(wl + k * 64 + c8 * 8 + 4);
+                    acc[0] = fmaf(w0[0], v[k], acc[0]); acc[1] = fmaf(w0[1], v[k], acc[1]); acc[2] = fmaf(w0[2], v[k], acc[2]); acc[3] = fmaf(w0[3], v[k], acc[3]);
+                    acc[4] = fmaf(w1[0], v[k], acc[4]); acc[5] = fmaf(w1[1], v[k], acc[5]); acc[6] = fmaf(w1[2], v[k], acc[6]); acc[7] = fmaf(w1[3], v[k], acc[7]);
+                }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
-            pair_store8(op + c8 * 8, op + 64 + c8 * 8, acc);
+                for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                pair_store8(op + c8 * 8, op + 64 + c8 * 8, acc);
+            }
         }
+        __syncthreads();
+        const size_t npx = total - base < 256 ? total - base : 256;
+        unsigned char* gout = (unsigned char*)out + base * 256;
+        for (unsigned int u = threadIdx.x; u < (unsigned int)npx * 16; u += 256)
+            *(u32x4*)(gout + (size_t)u * 16) = *(const u32x4*)(stage + (u >> 4) * 272 + (u & 15) * 16);
+        __syncthreads();
     }
 }
 hipError_t launch_pair_conv1_1(const uint8_t* rgb, int N, int Hi, int Wi, int H, int W, const float* w, const float* b, uint16_t* out, hipStream_t s) {

@@ -139,8 +139,10 @@ def roofline(reader, config, batch, steps):
                   "at 1280x960: conv1_1+conv1_2 fused .. upconv3.3x3 + upconv4.1x1(y) .. upconv4 fused .. conv_cls.4+tail)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
         # HBM bytes are not measurable from inside the process; the PMC passes of the same detector are committed under profiles/
-        # (r03_pmc_hbm.json, tools/pmc_traffic.py) -- a constant copied from a file would not be a measurement of THIS run
+        # (r04_pmc_hbm.json, tools/pmc_traffic.py) -- a constant copied from a file would not be a measurement of THIS run
         "traffic": None,
+        "traffic_profile": "profiles/r04_pmc_hbm.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over the same 25 launches, 32 pages, bf16): "
+                           "839 MB read + 499 MB written per page = 1.71 GB per launch, against ~1.1 GB per page algorithmic",
         "launches": conv_launches, "avg_launch_ms": conv_ms / max(conv_launches, 1),
         "algorithmic_gflop_per_page": conv_flops / 1e9 / max(batch * steps, 1),
         "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE[config],
