@@ -296,6 +296,34 @@ def leg_host_pages(reader, pages, batch, steps, resident_value, in_flight=2):
             "boxes_per_step": nb / steps, "leg_seconds": time.perf_counter() - t_leg}
 
 
+def leg_preprocess(reader, H=4284, W=5712, n=20):
+    """the reference's preprocess_for_book_cover chain on the device, one photograph-sized BGR page per call
+    (the reference's largest inputs are 5712x4284 phone photographs); seeded noise, resident in HBM.  Algorithmic bytes: one read + one write
+    of the plane per stage (5 B per source pixel for gray + the resize's read, 21 transfers of the 1.5x plane), DESIGN section 3."""
+    import numpy as np
+    import torch
+
+    from bb_ocr_amd import preprocess as dev_pp
+
+    t_leg = time.perf_counter()
+    bgr = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
+    for _ in range(2):
+        out = dev_pp.preprocess_bgr_device(reader, bgr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = dev_pp.preprocess_bgr_device(reader, bgr)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    plane = out.shape[0] * out.shape[1]
+    alg = H * W * 5 + 21 * plane      # gray 3 + 1, resize 1 + 1, blur 1 + 1, CLAHE 1 + (1 + 1), six box passes 2 each, unsharp 2 + 1 (tools/preprocess_bench.py)
+    return {"what": f"bbocr_preprocess_chain (gray, cubic 1.5x, blur, contrast+brightness LUT, CLAHE, unsharp) on one {W}x{H} BGR page -> "
+                    f"{out.shape[1]}x{out.shape[0]} gray plane, host-synchronous call, bit-identical to the CPU restatement (tests/test_gpu_ops.py)",
+            "value": 1e3 / ms, "unit": "pages/s", "ms_per_page": ms, "pages": n, "algorithmic_MB_per_page": alg / 1e6,
+            "roofline": {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": alg / ms / 1e6 / 8000.0, "traffic": None},
+            "leg_seconds": time.perf_counter() - t_leg}
+
+
 def leg_lowconf(reader, states, n_gpu_pages=16, n_cpu_pages=2, steps=3):
     """Low-confidence workload: faint-ink lines (synth.page(faint=0.5)) whose first-pass confidence falls under contrast_ths = 0.1, so that
     upstream's contrast retry (recognition.get_text: adjust_contrast_grey, second prediction, keep the better) is LIVE.  Timed on the card;
@@ -365,8 +393,8 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=16, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
-    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf",
-                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf; '' = none)")
+    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf,preprocess",
+                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf, preprocess; '' = none)")
     ap.add_argument("--leg-steps", type=int, default=6)
     ap.add_argument("--in-flight", type=int, default=2, help="calls in flight on the one Reader during the timed region (worker threads; bbocr_config::call_slots = 2)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
@@ -536,6 +564,9 @@ def main():
         if "host_pages" in names and args.config == "p1":
             legs["host_pages"] = leg_host_pages(reader, uniq, B, max(12, args.leg_steps), pages / dt, args.in_flight)
             log(f"leg host_pages: {legs['host_pages']['value']:.1f} images/s")
+        if "preprocess" in names:
+            legs["preprocess_f2"] = leg_preprocess(reader)
+            log(f"leg preprocess_f2: {legs['preprocess_f2']['ms_per_page']:.2f} ms per page")
         if "lowconf" in names and args.rec_weights == "trained":
             legs["lowconf"] = leg_lowconf(reader, (cs, rs))
             log(f"leg lowconf: retry {legs['lowconf']['contrast_retry_ms_per_step']:.2f} ms per step, texts {legs['lowconf']['texts_identical']}")
