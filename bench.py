@@ -546,6 +546,9 @@ def main():
             "weights": weights_path, "pages": pages_path,
         },
         "stage_ms_per_step_rank0": {k: v / args.steps for k, v in stage.items()},
+        "stage_ms_note": ("per CALL, from device events and host clocks inside that call; with more than one call in flight the stages of different calls overlap "
+                          "(their sum exceeds ms_per_step) and a stage queued behind the other call's detector includes that wait -- "
+                          "legs.serial holds the one-call-at-a-time breakdown") if args.in_flight > 1 else "one call at a time",
         "roofline": rf,
     }
     if world > 1:
