@@ -200,6 +200,14 @@ int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, in
     });
 }
 
+int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, uint8_t* dev_rgb, uint8_t* dev_gray) {
+    return guarded(ctx, [&](bbocr_ctx* ctx) {
+        if (!dev_ycc || !dev_rgb || npix == 0) fail(BBOCR_ERR_ARG, "bad colour-conversion arguments");
+        HIPCHK(launch_ycc_to_rgb_gray(dev_ycc, dev_rgb, dev_gray, npix, ctx->stream));
+        slot_sync(ctx, ctx->stream);
+    });
+}
+
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free, int imgW,
                    float contrast, uint16_t* dev_out, int* n_out, int mode) {
     return guarded(ctx, [&](bbocr_ctx* ctx) {

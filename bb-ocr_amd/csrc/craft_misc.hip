@@ -125,6 +125,34 @@ __global__ void __launch_bounds__(256) gray_kernel(const uint8_t* __restrict__ r
         gray[i] = (uint8_t)((c2 * 9798 + c1 * 19235 + c0 * 3735 + (1 << 14)) >> 15);
     }
 }
+// ---- libjpeg's YCbCr -> RGB (jdcolor.c::ycc_rgb_convert, the conversion behind every RGB decode of a JFIF file: cv2.imread, skimage /
+// PIL).  A JPEG decoded ONCE with out_color_space = JCS_YCbCr holds both planes upstream's path branch reads: its Y channel IS
+// cv2.imread(IMREAD_GRAYSCALE)'s plane (libjpeg decodes component 0 alone for JCS_GRAYSCALE, same IDCT), and the RGB image is this
+// pointwise integer map of the (fancy-upsampled) triple.  16-bit fixed point, FIX(x) = (int)(x * 65536 + 0.5), arithmetic shifts:
+//   R = y + ((FIX(1.40200) * (cr - 128) + 2^15) >> 16)
+//   G = y + ((-FIX(0.34414) * (cb - 128) + 2^15 - FIX(0.71414) * (cr - 128)) >> 16)
+//   B = y + ((FIX(1.77200) * (cb - 128) + 2^15) >> 16), each clamped to 0..255 (range_limit).
+__global__ void __launch_bounds__(256) ycc_to_rgb_gray_kernel(const uint8_t* __restrict__ ycc, uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray,
+                                                               size_t npix) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const int y = ycc[i * 3], cb = (int)ycc[i * 3 + 1] - 128, cr = (int)ycc[i * 3 + 2] - 128;
+        int r = y + ((91881 * cr + 32768) >> 16);
+        int g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+        int b = y + ((116130 * cb + 32768) >> 16);
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        g = g < 0 ? 0 : (g > 255 ? 255 : g);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        rgb[i * 3] = (uint8_t)r;
+        rgb[i * 3 + 1] = (uint8_t)g;
+        rgb[i * 3 + 2] = (uint8_t)b;
+        if (gray) gray[i] = (uint8_t)y;
+    }
+}
+hipError_t launch_ycc_to_rgb_gray(const uint8_t* ycc, uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {
+    const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+    hipLaunchKernelGGL(ycc_to_rgb_gray_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, ycc, rgb, gray, npix);
+    return hipGetLastError();
+}
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {
     const int grid = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(gray_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, rgb, gray, npix);

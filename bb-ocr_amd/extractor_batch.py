@@ -17,6 +17,32 @@ import os
 import numpy as np
 
 
+def _ocr_input(image_path, image_index=None, decode_once=True):
+    """``ocr_input_image`` for the batching loop: ``("ycc", triples, None)`` when the file easyocr would be given is a YCbCr-coded JPEG
+    (decoded once, RGB + Y plane derived on the card: reader.decode_file_ycc) -- every thumbnail is, it is written as one -- else
+    ``("rgb", rgb, gray)``."""
+    from PIL import Image
+
+    from .reader import decode_file, decode_file_ycc, reformat_input
+
+    cover = image_index is None or image_index == 0
+    max_dim = 1600 if cover else 2400
+    try:
+        img = Image.open(image_path)
+        if max(img.size) > max_dim:
+            img = img.convert("RGB")
+            img.thumbnail((max_dim, max_dim))
+            buf = io.BytesIO()
+            img.save(buf, format="JPEG", quality=(90 if cover else 95))
+            data = buf.getvalue()
+            ycc = decode_file_ycc(data) if decode_once else None
+            return ("ycc", ycc, None) if ycc is not None else ("rgb",) + tuple(decode_file(data))
+    except Exception:
+        pass                                                      # :511-514: any failure falls back to the original file
+    ycc = decode_file_ycc(os.fspath(image_path)) if decode_once else None
+    return ("ycc", ycc, None) if ycc is not None else ("rgb",) + tuple(reformat_input(os.fspath(image_path)))
+
+
 def ocr_input_image(image_path, image_index=None):
     """The pixels ``extract_text_with_ocr`` hands to easyocr for ``image_path`` (enhanced_extractor.py:486-512): pages whose
     longer side exceeds 1600 px (cover, ``image_index`` None or 0) / 2400 px (other pages) are ``Image.thumbnail``-ed to that
@@ -41,15 +67,17 @@ def ocr_input_image(image_path, image_index=None):
     return reformat_input(os.fspath(image_path))
 
 
-def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, decode_workers=None, **readtext_kw):
+def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, decode_workers=None, decode_once=True, **readtext_kw):
     """``{index: text}`` for every index of ``ocr_image_indices`` (default: all pages), text = ``" ".join(r[1] for r in results)``
     exactly as :521; a page whose OCR fails gets ``""`` like :529-531.  Pages of equal (down-scaled) shape travel in one device
     batch of at most ``max_batch`` pages.
 
     Decoding (and the thumbnail + JPEG round trip) is what bounds the application once the OCR itself runs at hundreds of pages
-    per second: a 1280x960 JPEG costs ~10 ms of one core.  The files are therefore decoded by ``decode_workers`` threads (default:
+    per second: a 1280x960 JPEG costs ~9 ms of one core decoded twice (RGB and the Y plane), ~4.6 ms decoded once into YCbCr triples
+    (reader.decode_file_ycc: both planes are then derived on the card).  The files are therefore decoded by ``decode_workers`` threads (default:
     the host's cores, at most 16; PIL releases the GIL while decoding) and a shape group is sent to the device as soon as it is
-    full, so the decode of later pages overlaps the device batch of earlier ones (ctypes releases the GIL during the C call)."""
+    full, so the decode of later pages overlaps the device batch of earlier ones (ctypes releases the GIL during the C call).
+    ``decode_once=False`` keeps the two-pass decode (RGB, then the Y plane) for JPEG pages: same results, for A/B timing."""
     import collections
     import queue
     import threading
@@ -74,7 +102,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
 
     def decode(i):
         try:
-            return ocr_input_image(image_paths[i], i)
+            return _ocr_input(image_paths[i], i, decode_once)
         except Exception:
             return None
 
@@ -83,7 +111,8 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
             by_shape = {}
 
             def flush(group):
-                batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), np.stack([p[2] for p in group])))
+                gray = None if group[0][2] is None else np.stack([p[2] for p in group])      # None: a group of once-decoded YCbCr pages
+                batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), gray))
                 for _ in group:
                     slots.release()
 
@@ -107,17 +136,22 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
                     if page is None:
                         slots.release()
                         continue
-                    rgb, gray = page
-                    group = by_shape.setdefault(rgb.shape, [])
+                    kind, rgb, gray = page                          # kind "ycc": rgb holds the YCbCr triples, gray is None
+                    key = (kind, rgb.shape)
+                    group = by_shape.setdefault(key, [])
                     group.append((i, rgb, gray))
                     if len(group) >= max_batch:
-                        flush(by_shape.pop(rgb.shape))
-                    elif not slots.acquire(blocking=False):
-                        # every slot is held by pages waiting in partial groups (many distinct shapes): send the largest one
-                        big = max(by_shape, key=lambda k: len(by_shape[k]))
-                        flush(by_shape.pop(big))
-                    else:
-                        slots.release()
+                        flush(by_shape.pop(key))
+                    elif not pending and not done_submitting:
+                        # nothing is being decoded: the next submission needs a slot.  If every slot is held by pages waiting in partial
+                        # groups (many distinct shapes), send the largest group -- only then: while decodes are pending their pages hold
+                        # slots too, and flushing on that account cut full batches into single pages (round 3: the faster the decode
+                        # pool, the smaller the device batches)
+                        if slots.acquire(blocking=False):
+                            slots.release()
+                        else:
+                            big = max(by_shape, key=lambda k: len(by_shape[k]))
+                            flush(by_shape.pop(big))
                 for group in by_shape.values():
                     if group:
                         flush(group)
@@ -126,14 +160,15 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
 
     def ocr(item):
         ids, rgb, gray = item
+        read = (lambda a, g: reader.readtext_ycc_arrays(a, **readtext_kw)) if gray is None else (lambda a, g: reader.readtext_arrays(a, g, **readtext_kw))
         try:
-            res = reader.readtext_arrays(rgb, gray, **readtext_kw)
+            res = read(rgb, gray)
         except Exception:
             # the reference loses ONE page when its OCR fails (enhanced_extractor.py:529-531): retry the batch page by page
             res = []
             for k in range(len(ids)):
                 try:
-                    res.append(reader.readtext_arrays(rgb[k:k + 1], gray[k:k + 1], **readtext_kw)[0])
+                    res.append(read(rgb[k:k + 1], None if gray is None else gray[k:k + 1])[0])
                 except Exception:
                     res.append([])
         for i, r in zip(ids, res):

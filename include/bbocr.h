@@ -250,6 +250,11 @@ int bbocr_op_ctc(bbocr_ctx* ctx, const float* dev_logits, int n, int T, int C, i
                  const unsigned int* ignore_mask, int beam_width);
 /* cv2.resize(INTER_LINEAR) on uint8 [N,sh,sw,C] -> [N,dh,dw,C] (device) */
 int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, int sw, int C, uint8_t* dev_dst, int dh, int dw);
+/* JPEG pages decoded ONCE on the host into libjpeg's YCbCr triples (out_color_space = JCS_YCbCr; PIL: draft("YCbCr")): uint8 [npix,3]
+ * (device) -> the RGB image libjpeg's own ycc_rgb_convert yields (what skimage / cv2.imread hand easyocr.utils.reformat_input,
+ * reader.readtext at enhanced_extractor.py:520) and, when dev_gray is not NULL, the Y plane = cv2.imread(IMREAD_GRAYSCALE)'s
+ * plane; both bit for bit (tests/test_oracle_cpu.py pins the formula against the decoder) */
+int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, uint8_t* dev_rgb, uint8_t* dev_gray);
 /* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] (in box order); returns their count in *n_out.
  * contrast != 0 applies adjust_contrast_grey first.  mode 0: the boxes whose own padded width is imgW (Reader.recognize's per-box
  * branch); mode 1..4: EVERY box at the forced width imgW, rotated by np.rot90(crop, mode - 1) (the batched branch rotation_info takes) */

@@ -54,6 +54,24 @@ def decode_file(path):
     return rgb, ((r * 9797 + g * 19234 + b * 3737) >> 15).astype(np.uint8)
 
 
+def jpeg_ycc_to_rgb(ycc: np.ndarray) -> np.ndarray:
+    """libjpeg jdcolor.c::ycc_rgb_convert + build_ycc_rgb_table (libjpeg 6b API, shipped as libjpeg-turbo with Pillow / OpenCV; its SIMD
+    paths are bit-exact with this C code): uint8 [..., 3] YCbCr -> uint8 [..., 3] RGB.  SCALEBITS = 16, FIX(x) = (int)(x * 65536 + 0.5),
+    Cr_r = (FIX(1.40200) x + 2^15) >> 16, Cb_b = (FIX(1.77200) x + 2^15) >> 16, Cr_g = -FIX(0.71414) x, Cb_g = -FIX(0.34414) x + 2^15
+    (x = sample - 128, arithmetic shifts), G = y + ((Cb_g + Cr_g) >> 16), range-limited.  Pinned against the decoder itself in
+    tests/test_oracle_cpu.py (one YCbCr decode == the RGB decode and the Y-plane decode of the same file)."""
+    fix = lambda v: int(v * 65536 + 0.5)
+    x = np.arange(256, dtype=np.int64) - 128
+    cr_r = (fix(1.40200) * x + 32768) >> 16
+    cb_b = (fix(1.77200) * x + 32768) >> 16
+    cr_g = -fix(0.71414) * x
+    cb_g = -fix(0.34414) * x + 32768
+    y = ycc[..., 0].astype(np.int64)
+    cb, cr = ycc[..., 1], ycc[..., 2]
+    out = np.stack([y + cr_r[cr], y + ((cb_g[cb] + cr_g[cr]) >> 16), y + cb_b[cb]], axis=-1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def reformat_input(image):
     """easyocr/utils.py::reformat_input -> (img RGB uint8 HWC, img_cv_grey uint8 HW).
 

@@ -288,6 +288,50 @@ def test_path_inputs_follow_the_stated_gray_rule(tmp_path):
     assert bb_ocr_amd.reformat_input(px)[1].tolist() == [[29, 150, 76, 142, 255]]
 
 
+def test_one_ycbcr_decode_holds_both_planes_of_a_jpeg(tmp_path):
+    """a2, decode once: libjpeg's YCbCr triples of a JFIF file give, bit for bit, the RGB decode (through jdcolor.c's integer conversion,
+    restated in oracle/imgproc.py::jpeg_ycc_to_rgb and run on the card by bbocr_op_ycc_to_rgb) and the grayscale decode (their Y channel).
+    Pinned against the decoder itself: every subsampling / quality / progressive variant, and the reference's own photographs."""
+    import glob
+    import io
+    import os
+
+    from PIL import Image
+
+    from bb_ocr_amd.reader import decode_file, decode_file_ycc
+    from oracle import imgproc
+
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (120, 168, 3), dtype=np.uint8)
+    ramp = (np.add.outer(np.arange(120), np.arange(168))[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8)
+    sat = np.kron(rng.integers(0, 2, (15, 21, 3), dtype=np.uint8) * 255, np.ones((8, 8, 1), dtype=np.uint8))    # saturated colours: the clamps
+    n = 0
+    for img in (noise, ramp, sat):
+        for kw in (dict(quality=92), dict(quality=100, subsampling=0), dict(quality=75, subsampling=1), dict(quality=95, subsampling=2),
+                   dict(quality=90, progressive=True), dict(quality=30, optimize=True)):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", **kw)
+            ycc = decode_file_ycc(buf.getvalue())
+            rgb, grey = decode_file(buf.getvalue())
+            assert ycc is not None and np.array_equal(imgproc.jpeg_ycc_to_rgb(ycc), rgb) and np.array_equal(ycc[..., 0], grey), kw
+            n += 1
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "photos")
+    for path in sorted(glob.glob(os.path.join(here, "*.JPG")))[:2]:
+        ycc = decode_file_ycc(path)
+        rgb, grey = decode_file(path)
+        assert ycc is not None and np.array_equal(imgproc.jpeg_ycc_to_rgb(ycc), rgb) and np.array_equal(ycc[..., 0], grey)
+    # files the single decode does not take: other containers, greyscale and CMYK JPEGs (callers fall back to decode_file)
+    png, gj, cj = (str(tmp_path / f) for f in ("a.png", "g.jpg", "c.jpg"))
+    Image.fromarray(noise).save(png)
+    Image.fromarray(noise[..., 0]).save(gj)
+    Image.fromarray(noise).convert("CMYK").save(cj)
+    assert decode_file_ycc(png) is None and decode_file_ycc(gj) is None and decode_file_ycc(cj) is None
+    assert decode_file_ycc(str(tmp_path / "missing.jpg")) is None and decode_file_ycc(b"not a jpeg") is None
+    # known answers of the conversion: grey stays grey, the primaries' chroma clamps
+    px = np.array([[[128, 128, 128], [0, 128, 128], [255, 128, 128], [76, 85, 255], [150, 44, 21], [29, 255, 107]]], dtype=np.uint8)
+    assert imgproc.jpeg_ycc_to_rgb(px).tolist() == [[[128, 128, 128], [0, 0, 0], [255, 255, 255], [254, 0, 0], [0, 255, 1], [0, 0, 254]]]
+
+
 def test_shard_range_partitions_exactly():
     from bb_ocr_amd import dist
 
@@ -372,11 +416,20 @@ def test_extractor_downscale_rule_and_batching(tmp_path):
                 raise RuntimeError("boom")             # a batch holding the bad page fails as a whole ...
             return [[(None, f"w{rgb.shape[2]}", 0.9), (None, "x", 0.5)] for _ in range(rgb.shape[0])]
 
+        def readtext_ycc_arrays(self, ycc, **kw):      # thumbnails are JPEGs: decoded once, colour conversion left to the card
+            self.ycc_pages = getattr(self, "ycc_pages", 0) + ycc.shape[0]
+            return self.readtext_arrays(ycc, None, **kw)
+
     fr = FakeReader()
     texts = eb.extract_texts(fr, [big, small, big, tmp_path / "missing.png", good], [1, 2, 0, 3, 7, 4])
     # ... and is retried page by page: only the bad page maps to empty text, like the reference's per-page except (:529-531)
     assert texts == {1: "", 2: "w2400 x", 0: "w1600 x", 3: "", 4: "w400 x"}
     assert sorted(fr.batches) == sorted([(2, 300, 400, 3), (1, 300, 400, 3), (1, 300, 400, 3), (1, 800, 2400, 3), (1, 533, 1600, 3)])
+    assert fr.ycc_pages == 2                           # the two thumbnails; the PNG pages travel as (rgb, gray)
+    kind, ycc0, none = eb._ocr_input(big, 0)
+    from oracle import imgproc
+    assert kind == "ycc" and none is None and np.array_equal(imgproc.jpeg_ycc_to_rgb(ycc0), rgb0) and np.array_equal(ycc0[..., 0], g0)
+    assert eb._ocr_input(small, 0)[0] == "rgb"
     # back-pressure: many files, tiny batches -- every page still comes out once, in any order
     many = [good] * 37
     fr2 = FakeReader()

@@ -122,6 +122,20 @@ def test_resize_u8_bit_exact(reader):
             assert np.array_equal(got[n] if c > 1 else got[n, :, :, 0], ref), (sh, sw, dh, dw, c)
 
 
+def test_jpeg_colour_conversion_on_device_is_libjpegs(reader):
+    """a2, decode once: bbocr_op_ycc_to_rgb on ALL 2^24 (Y, Cb, Cr) triples against the restatement of jdcolor.c (which the CPU suite pins
+    against the decoder): RGB bit for bit, gray = the Y channel."""
+    from oracle import imgproc
+
+    v = np.arange(256, dtype=np.uint8)
+    ycc = np.stack(np.meshgrid(v, v, v, indexing="ij"), axis=-1).reshape(1, 4096, 4096, 3)
+    rgb, gray = reader.pages_from_ycc(torch.from_numpy(np.ascontiguousarray(ycc)).cuda())
+    assert np.array_equal(gray.cpu().numpy(), ycc[..., 0])
+    assert np.array_equal(rgb.cpu().numpy(), imgproc.jpeg_ycc_to_rgb(ycc))
+    with pytest.raises(ValueError):
+        reader.pages_from_ycc(torch.zeros((1, 4, 4, 4), dtype=torch.uint8, device="cuda"))
+
+
 def test_ctc_matches_oracle(reader):
     from oracle import recog
 

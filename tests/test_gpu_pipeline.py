@@ -483,9 +483,19 @@ def test_extractor_batching_and_tesseract_shim(reader, tmp_path):
         p = tmp_path / f"p{i}.png"
         Image.fromarray(img).save(p)
         paths.append(p)
+    for i in range(3):                                  # JPEG pages: decoded ONCE by the batching loop (YCbCr triples, RGB + Y plane derived on the
+        img, _ = synth.page(310 + i, width=640, height=384, lines=5, margin=24)       # card), twice by readtext(path) -- same strings
+        p = tmp_path / f"j{i}.jpg"
+        Image.fromarray(img).save(p, quality=(92, 75, 100)[i], subsampling=(2, 1, 0)[i])
+        paths.append(p)
+    assert eb._ocr_input(paths[3], 3)[0] == "ycc" and eb._ocr_input(paths[0], 0)[0] == "rgb"
     texts = eb.extract_texts(reader, paths)
     for i, p in enumerate(paths):
-        assert texts[i] == " ".join(r[1] for r in reader.readtext(str(p)))
+        assert texts[i] == " ".join(r[1] for r in reader.readtext(str(p))) and texts[i]
+    from bb_ocr_amd.reader import decode_file, decode_file_ycc
+    a, g = decode_file(str(paths[4]))
+    want = reader.readtext_arrays(a[None], g[None])
+    assert reader.readtext_ycc_arrays(decode_file_ycc(str(paths[4]))[None]) == want       # boxes, strings and confidences
     s = ts.image_to_string(Image.open(paths[0]), reader=reader)
     assert s.endswith("\n") and len(s.strip().split("\n")) == 5
 

@@ -23,12 +23,16 @@ with tempfile.TemporaryDirectory() as d:
     dec = (time.perf_counter() - t0) / 16
     extractor_batch.extract_texts(r, paths[:64], decode_workers=workers)          # warm-up
     bb_ocr_amd.freeze_gc()
+    ref = None
     for w in ([workers] if workers else [1, 4, 8, 16]):
-        t0 = time.perf_counter()
-        texts = extractor_batch.extract_texts(r, paths, decode_workers=w)
-        dt = time.perf_counter() - t0
-        print(f"{n} JPEG pages 1280x960, {w} decode threads: {dt*1e3:.0f} ms = {n/dt:.1f} pages/s "
-              f"(single-thread JPEG decode {dec*1e3:.1f} ms/page; cores {os.cpu_count()}; non-empty texts {sum(bool(t) for t in texts.values())})")
+        for once in (False, True, False, True):            # each arm twice, alternating
+            t0 = time.perf_counter()
+            texts = extractor_batch.extract_texts(r, paths, decode_workers=w, decode_once=once)
+            dt = time.perf_counter() - t0
+            ref = ref or texts
+            print(f"{n} JPEG pages 1280x960, {w} decode threads, {'ONE YCbCr decode per page' if once else 'two decodes per page (RGB + Y)'}: "
+                  f"{dt*1e3:.0f} ms = {n/dt:.1f} pages/s (single-thread RGB decode {dec*1e3:.1f} ms/page; cores {os.cpu_count()}; "
+                  f"non-empty texts {sum(bool(t) for t in texts.values())}; texts equal to the first run's: {texts == ref})", flush=True)
     # host arrays in (no decode): the PCIe-inclusive rate of the readtext boundary
     host = np.stack([uniq[i % 8] for i in range(64)])
     r.readtext_arrays(host)
