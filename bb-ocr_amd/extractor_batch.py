@@ -90,9 +90,15 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
     if not idxs:
         return texts
     if decode_workers is None:
-        decode_workers = max(1, min(8, os.cpu_count() or 1, len(idxs)))
+        # a third of the process's CPU share (affinity mask and cgroup quota, bbocr_host_cpu_share), at most 8: the library's own host pool and
+        # the two device-call threads need the rest -- on a 16-CPU share 4-5 decode threads gave the steadiest rate, 8 and 16 a noisier one
+        try:
+            share = int(reader._lib.bbocr_host_cpu_share())
+        except Exception:
+            share = os.cpu_count() or 1
+        decode_workers = max(1, min(8, share // 3, len(idxs)))
 
-    # three overlapped stages: decode pool -> assembler thread (groups pages by shape, stacks a full group into one host batch)
+    # three overlapped stages: decode pool -> assembler thread (groups pages by shape, hands a full group on as one batch)
     # -> this thread (device call + result strings).  Back-pressure end to end: at most `window` decoded pages exist outside the two
     # assembled batches the queue may hold (a decode is only submitted once a slot is free, and a slot is released when its page has
     # been copied into a batch), so the resident set is bounded by ~4 batches however many files are queued.
@@ -111,8 +117,9 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
             by_shape = {}
 
             def flush(group):
-                gray = None if group[0][2] is None else np.stack([p[2] for p in group])      # None: a group of once-decoded YCbCr pages
-                batches.put(([p[0] for p in group], np.stack([p[1] for p in group]), gray))
+                # pages travel as LISTS: the Reader uploads them one by one into the device batch (no 236-MB np.stack on this thread)
+                gray = None if group[0][2] is None else [p[2] for p in group]                 # None: a group of once-decoded YCbCr pages
+                batches.put(([p[0] for p in group], [p[1] for p in group], gray))
                 for _ in group:
                     slots.release()
 

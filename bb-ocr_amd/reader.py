@@ -260,6 +260,19 @@ def auto_host_threads(local_world=None, cpus=None):
     return max(1, min(16, cpus // local_world))
 
 
+def _as_tensor(torch, a):
+    """CPU tensor sharing ``a``'s memory, as the SOURCE of a copy.  Arrays decoded by PIL are read-only views of a bytes object; torch only
+    warns about those because a write through the tensor would be undefined -- nothing here writes, so the warning is silenced for this
+    one call instead of paying a 3.7-MB copy per page to make the array writable."""
+    if a.flags.writeable:
+        return torch.from_numpy(a)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(a)
+
+
 class Reader:
     """Drop-in for ``easyocr.Reader`` (English ``english_g2`` recogniser + CRAFT detector) on one MI355X."""
 
@@ -380,11 +393,22 @@ class Reader:
         return p
 
     def _to_dev(self, arr):
+        """Host array -> device tensor; a LIST of equal-shape arrays -> one device tensor ``[len, ...]`` filled page by page (no host-side
+        ``np.stack``: for 64 decoded pages that copy is 236 MB on one thread, the largest serial cost of a decode-bound caller)."""
+        torch = self._torch
+        if isinstance(arr, (list, tuple)):
+            first = np.asarray(arr[0])
+            t = torch.empty((len(arr),) + first.shape, dtype=torch.uint8, device=self.device)
+            for k, a in enumerate(arr):
+                a = np.ascontiguousarray(a)
+                if a.dtype != np.uint8 or a.shape != first.shape:
+                    raise ValueError("pages of one batch must be uint8 arrays of one shape")
+                t[k].copy_(_as_tensor(torch, a))
+            torch.cuda.current_stream(self.device_index).synchronize()
+            return t
         arr = np.ascontiguousarray(arr)
-        if not arr.flags.writeable:          # e.g. a view of a PIL image: torch wants a writable source
-            arr = arr.copy()
-        t = self._torch.from_numpy(arr).to(self.device)
-        self._torch.cuda.current_stream(self.device_index).synchronize()
+        t = _as_tensor(torch, arr).to(self.device)
+        torch.cuda.current_stream(self.device_index).synchronize()
         return t
 
     def _dev_u8(self, t, name, ndim, shape=None):
@@ -489,9 +513,10 @@ class Reader:
     def readtext_ycc_arrays(self, ycc, **kw):
         """Host array ``uint8 [B,H,W,3]`` of once-decoded JPEG pages (``decode_file_ycc``) -> per-page results, identical to
         ``readtext_arrays(rgb, gray)`` of the same files decoded twice."""
-        ycc = np.asarray(ycc)
-        if ycc.dtype != np.uint8 or ycc.ndim != 4 or ycc.shape[3] != 3:
-            raise ValueError("readtext_ycc_arrays expects uint8 [B,H,W,3]")
+        if not isinstance(ycc, (list, tuple)):               # a list of [H,W,3] pages is uploaded page by page (Reader._to_dev)
+            ycc = np.asarray(ycc)
+            if ycc.dtype != np.uint8 or ycc.ndim != 4 or ycc.shape[3] != 3:
+                raise ValueError("readtext_ycc_arrays expects uint8 [B,H,W,3]")
         rgb, gray = self.pages_from_ycc(self._to_dev(ycc))
         return self.readtext_device(rgb, gray, **kw)
 
@@ -563,6 +588,10 @@ class Reader:
 
     def readtext_arrays(self, rgb, gray=None, **kw):
         """Host arrays ``uint8 [B,H,W,3]`` (+ optional ``[B,H,W]`` gray planes, else derived on device) -> per-page results."""
+        if isinstance(rgb, (list, tuple)):                   # lists of [H,W,3] (+ [H,W]) pages: uploaded page by page (Reader._to_dev)
+            if gray is not None and len(gray) != len(rgb):
+                raise ValueError("readtext_arrays: one gray plane per page")
+            return self.readtext_device(self._to_dev(rgb), self._to_dev(gray) if gray is not None else None, **kw)
         rgb = np.asarray(rgb)
         if rgb.dtype != np.uint8 or rgb.ndim != 4 or rgb.shape[3] != 3:
             raise ValueError("readtext_arrays expects uint8 [B,H,W,3]")

@@ -411,13 +411,14 @@ def test_extractor_downscale_rule_and_batching(tmp_path):
             self.batches = []
 
         def readtext_arrays(self, rgb, gray=None, **kw):
+            rgb = np.stack(rgb)                        # the batching loop hands over LISTS of equal-shape pages
             self.batches.append(rgb.shape)
             if any(p[0, 0].tolist() == poison for p in rgb):
                 raise RuntimeError("boom")             # a batch holding the bad page fails as a whole ...
             return [[(None, f"w{rgb.shape[2]}", 0.9), (None, "x", 0.5)] for _ in range(rgb.shape[0])]
 
         def readtext_ycc_arrays(self, ycc, **kw):      # thumbnails are JPEGs: decoded once, colour conversion left to the card
-            self.ycc_pages = getattr(self, "ycc_pages", 0) + ycc.shape[0]
+            self.ycc_pages = getattr(self, "ycc_pages", 0) + len(ycc)
             return self.readtext_arrays(ycc, None, **kw)
 
     fr = FakeReader()
