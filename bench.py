@@ -296,6 +296,34 @@ def leg_host_pages(reader, pages, batch, steps, resident_value, in_flight=2):
             "boxes_per_step": nb / steps, "leg_seconds": time.perf_counter() - t_leg}
 
 
+def leg_extractor(reader, pages, n=512):
+    """SURVEY section 8 row f3, the application's own loop: a directory of JPEG files -> extractor_batch.extract_texts -> {index: text}
+    (file read + JPEG decode on the host pool + H2D + the whole OCR path + the joined strings of enhanced_extractor.py:521) -- everything
+    the reference's per-page loop at :680-688 does for its OCR step, batched.  PCIe- and decode-inclusive, never the headline value."""
+    import tempfile
+
+    from PIL import Image
+
+    from bb_ocr_amd import extractor_batch
+
+    t_leg = time.perf_counter()
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i in range(min(len(pages), 16)):
+            p = os.path.join(d, f"page_{i:03d}.jpg")
+            Image.fromarray(pages[i]).save(p, quality=92)
+            paths.append(p)
+        paths = [paths[i % len(paths)] for i in range(n)]
+        extractor_batch.extract_texts(reader, paths[:128])
+        t0 = time.perf_counter()
+        texts = extractor_batch.extract_texts(reader, paths)
+        dt = time.perf_counter() - t0
+    return {"what": f"{n} JPEG files (1280x960, quality 92) -> extractor_batch.extract_texts: decode pool (one YCbCr decode per page, RGB + Y plane "
+                    f"derived on the card), page-by-page H2D, two device batches in flight, joined strings",
+            "value": n / dt, "unit": "images/s", "pages": n, "non_empty_texts": sum(bool(t) for t in texts.values()), "host_cores": host_cores(),
+            "leg_seconds": time.perf_counter() - t_leg}
+
+
 def leg_preprocess(reader, H=4284, W=5712, n=20):
     """the reference's preprocess_for_book_cover chain on the device, one photograph-sized BGR page per call
     (the reference's largest inputs are 5712x4284 phone photographs); seeded noise, resident in HBM.  Algorithmic bytes: one read + one write
@@ -393,8 +421,8 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=16, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
-    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf,preprocess",
-                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf, preprocess; '' = none)")
+    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf,preprocess,extractor",
+                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf, preprocess, extractor; '' = none)")
     ap.add_argument("--leg-steps", type=int, default=6)
     ap.add_argument("--in-flight", type=int, default=2, help="calls in flight on the one Reader during the timed region (worker threads; bbocr_config::call_slots = 2)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
@@ -567,6 +595,9 @@ def main():
         if "host_pages" in names and args.config == "p1":
             legs["host_pages"] = leg_host_pages(reader, uniq, B, max(12, args.leg_steps), pages / dt, args.in_flight)
             log(f"leg host_pages: {legs['host_pages']['value']:.1f} images/s")
+        if "extractor" in names and args.config == "p1":
+            legs["extractor_jpeg"] = leg_extractor(reader, uniq)
+            log(f"leg extractor_jpeg: {legs['extractor_jpeg']['value']:.1f} images/s")
         if "preprocess" in names:
             legs["preprocess_f2"] = leg_preprocess(reader)
             log(f"leg preprocess_f2: {legs['preprocess_f2']['ms_per_page']:.2f} ms per page")
