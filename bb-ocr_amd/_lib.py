@@ -99,7 +99,8 @@ PROTOTYPES = {
     "bbocr_op_ctc": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                C.POINTER(C.c_uint), C.c_int]),
     "bbocr_op_resize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
-    "bbocr_op_ycc_to_rgb": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "bbocr_op_ycc_to_rgb": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "bbocr_upload_pages": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, _vp]),
     "bbocr_op_crops": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_float,
                                  _vp, C.POINTER(C.c_int), C.c_int]),
     "bbocr_preprocess_book_cover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -127,6 +127,7 @@ void bbocr_destroy(bbocr_ctx* c) {
     free_weights(c);
     slot_destroy(c);
     if (c->zero_page) (void)hipFree(c->zero_page);
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -200,12 +200,40 @@ int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, in
     });
 }
 
-int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, uint8_t* dev_rgb, uint8_t* dev_gray) {
+int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, int pixel_stride, uint8_t* dev_rgb, uint8_t* dev_gray) {
     return guarded(ctx, [&](bbocr_ctx* ctx) {
-        if (!dev_ycc || !dev_rgb || npix == 0) fail(BBOCR_ERR_ARG, "bad colour-conversion arguments");
-        HIPCHK(launch_ycc_to_rgb_gray(dev_ycc, dev_rgb, dev_gray, npix, ctx->stream));
+        if (!dev_ycc || !dev_rgb || npix == 0 || (pixel_stride != 3 && pixel_stride != 4)) fail(BBOCR_ERR_ARG, "bad colour-conversion arguments");
+        HIPCHK(launch_ycc_to_rgb_gray(dev_ycc, pixel_stride, dev_rgb, dev_gray, npix, ctx->stream));
         slot_sync(ctx, ctx->stream);
     });
+}
+
+int bbocr_upload_pages(bbocr_ctx* root, const void* const* host_pages, int n, size_t bytes_each, void* dev_dst) {
+    // NOT a call slot's work: an upload stage feeding two calls in flight must not wait for one of them to return.  Own stream, one upload at
+    // a time per context; errors reported like every other entry point's.
+    if (!root) return BBOCR_ERR_ARG;
+    auto set_err = [&](const std::string& m) {
+        std::lock_guard<std::mutex> lk(root->pool_mu);
+        root->err = m;
+    };
+    try {
+        if (!host_pages || !dev_dst || n <= 0 || bytes_each == 0) fail(BBOCR_ERR_ARG, "bad upload arguments");
+        HIPCHK(hipSetDevice(root->cfg.device));
+        std::lock_guard<std::mutex> up(root->upload_mu);
+        if (!root->upload_stream) HIPCHK(hipStreamCreateWithFlags(&root->upload_stream, hipStreamNonBlocking));
+        for (int k = 0; k < n; ++k) {
+            if (!host_pages[k]) fail(BBOCR_ERR_ARG, "null page");
+            HIPCHK(hipMemcpyAsync((unsigned char*)dev_dst + (size_t)k * bytes_each, host_pages[k], bytes_each, hipMemcpyHostToDevice, root->upload_stream));
+        }
+        HIPCHK(hipStreamSynchronize(root->upload_stream));
+        return BBOCR_OK;
+    } catch (const StatusError& se) {
+        set_err(se.msg);
+        return se.code;
+    } catch (const std::exception& ex) {
+        set_err(ex.what());
+        return BBOCR_ERR_INTERNAL;
+    }
 }
 
 int bbocr_op_crops(bbocr_ctx* ctx, const uint8_t* dev_gray, int H, int W, const int* hori, int n_hori, const double* free_q, int n_free, int imgW,

@@ -132,10 +132,17 @@ __global__ void __launch_bounds__(256) gray_kernel(const uint8_t* __restrict__ r
 //   R = y + ((FIX(1.40200) * (cr - 128) + 2^15) >> 16)
 //   G = y + ((-FIX(0.34414) * (cb - 128) + 2^15 - FIX(0.71414) * (cr - 128)) >> 16)
 //   B = y + ((FIX(1.77200) * (cb - 128) + 2^15) >> 16), each clamped to 0..255 (range_limit).
-__global__ void __launch_bounds__(256) ycc_to_rgb_gray_kernel(const uint8_t* __restrict__ ycc, uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray,
-                                                               size_t npix) {
+// `stride` = bytes per source pixel: 3 (tight triples) or 4 (Pillow's own pixel storage, Y Cb Cr x, taken zero-copy: one dword load)
+__global__ void __launch_bounds__(256) ycc_to_rgb_gray_kernel(const uint8_t* __restrict__ ycc, int stride, uint8_t* __restrict__ rgb,
+                                                               uint8_t* __restrict__ gray, size_t npix) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-        const int y = ycc[i * 3], cb = (int)ycc[i * 3 + 1] - 128, cr = (int)ycc[i * 3 + 2] - 128;
+        int y, cb, cr;
+        if (stride == 4) {
+            const unsigned int p = ((const unsigned int*)ycc)[i];
+            y = (int)(p & 255u); cb = (int)((p >> 8) & 255u) - 128; cr = (int)((p >> 16) & 255u) - 128;
+        } else {
+            y = ycc[i * 3]; cb = (int)ycc[i * 3 + 1] - 128; cr = (int)ycc[i * 3 + 2] - 128;
+        }
         int r = y + ((91881 * cr + 32768) >> 16);
         int g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
         int b = y + ((116130 * cb + 32768) >> 16);
@@ -148,9 +155,10 @@ __global__ void __launch_bounds__(256) ycc_to_rgb_gray_kernel(const uint8_t* __r
         if (gray) gray[i] = (uint8_t)y;
     }
 }
-hipError_t launch_ycc_to_rgb_gray(const uint8_t* ycc, uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {
+hipError_t launch_ycc_to_rgb_gray(const uint8_t* ycc, int stride, uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {
+    if ((stride != 3 && stride != 4) || (stride == 4 && ((size_t)ycc & 3))) return hipErrorInvalidValue;
     const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
-    hipLaunchKernelGGL(ycc_to_rgb_gray_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, ycc, rgb, gray, npix);
+    hipLaunchKernelGGL(ycc_to_rgb_gray_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, ycc, stride, rgb, gray, npix);
     return hipGetLastError();
 }
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s) {

@@ -163,6 +163,8 @@ struct bbocr_ctx : WeightView {
     unsigned int ignore_mask[4] = {0, 0, 0, 0};   // recogniser class mask of the running call (bbocr_params::ignore_mask)
     int beam_width = 0;                           // > 0: decoder='beamsearch' for the running call (bbocr_params::decoder / beam_width)
     hipStream_t cur = nullptr;                // stream the layer helpers launch on
+    hipStream_t upload_stream = nullptr;      // root only: bbocr_upload_pages copies here, outside the call slots (an upload never waits for a running call)
+    std::mutex upload_mu;
     hipStream_t seq_stream = nullptr;         // per slot: the recogniser's SEQUENCE stage (projections, BiLSTMs, linears, CTC, read-back) -- latency-bound
                                               // launches of 100-300 workgroups that leave most of the card idle -- runs here, behind an event of this
                                               // slot's feature parts, so that it overlaps the OTHER call's detector instead of queueing in front of it

@@ -83,7 +83,7 @@ void pack_conv1_1_weights_fused(const float* w /*[64][3][3][3] folded*/, uint16_
 hipError_t launch_maxpool(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int relu_in, hipStream_t s);
 hipError_t launch_gray(const uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
-hipError_t launch_ycc_to_rgb_gray(const uint8_t* ycc, uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
+hipError_t launch_ycc_to_rgb_gray(const uint8_t* ycc, int stride, uint8_t* rgb, uint8_t* gray, size_t npix, hipStream_t s);
 hipError_t launch_resize_u8(const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw, hipStream_t s);
 
 // ------------------------------------------------------------------ exact detector, element-wise helpers on pair tensors (craft_pair.hip)

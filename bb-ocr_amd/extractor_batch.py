@@ -35,11 +35,11 @@ def _ocr_input(image_path, image_index=None, decode_once=True):
             buf = io.BytesIO()
             img.save(buf, format="JPEG", quality=(90 if cover else 95))
             data = buf.getvalue()
-            ycc = decode_file_ycc(data) if decode_once else None
+            ycc = decode_file_ycc(data, padded=True) if decode_once else None
             return ("ycc", ycc, None) if ycc is not None else ("rgb",) + tuple(decode_file(data))
     except Exception:
         pass                                                      # :511-514: any failure falls back to the original file
-    ycc = decode_file_ycc(os.fspath(image_path)) if decode_once else None
+    ycc = decode_file_ycc(os.fspath(image_path), padded=True) if decode_once else None
     return ("ycc", ycc, None) if ycc is not None else ("rgb",) + tuple(reformat_input(os.fspath(image_path)))
 
 
@@ -165,8 +165,35 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
         finally:
             batches.put(None)
 
-    def ocr(item):
+    def upload(item):
+        """Stage between the assembler and the device calls: the batch's pages reach the card (one GIL-free C call on the context's upload
+        stream, outside the call slots) while both device workers are still inside their calls -- a worker that uploaded its own batch left
+        the card idle for that long, and the two workers fell into step.  Readers without the upload entry (test doubles) pass through."""
         ids, rgb, gray = item
+        to_dev = getattr(reader, "_to_dev", None)
+        if to_dev is None:
+            return item
+        try:
+            return ids, to_dev(rgb), (to_dev(gray) if gray is not None else None), rgb, gray
+        except Exception:
+            return item                                  # the device worker retries from the host pages and reports per page
+
+    def ocr(item):
+        if len(item) == 5:                               # uploaded: device tensors + the host pages for the page-by-page retry
+            ids, rgb_dev, gray_dev, rgb, gray = item
+            try:
+                if gray is None:
+                    res = reader.readtext_device(*reader.pages_from_ycc(rgb_dev), **readtext_kw)
+                else:
+                    res = reader.readtext_device(rgb_dev, gray_dev, **readtext_kw)
+                for i, r in zip(ids, res):
+                    texts[i] = " ".join(t[1] for t in r)
+                return
+            except Exception:
+                pass
+            del rgb_dev, gray_dev
+        else:
+            ids, rgb, gray = item
         read = (lambda a, g: reader.readtext_ycc_arrays(a, **readtext_kw)) if gray is None else (lambda a, g: reader.readtext_arrays(a, g, **readtext_kw))
         try:
             res = read(rgb, gray)
@@ -192,6 +219,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
             item = batches.get()
             if item is None:
                 break
+            item = upload(item)                          # this thread is the upload stage: it runs one batch ahead of the device workers
             in_flight.acquire()
             fut = device_pool.submit(ocr, item)
             fut.add_done_callback(lambda _f: in_flight.release())

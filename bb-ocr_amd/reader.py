@@ -97,12 +97,31 @@ def decode_file(source, parallel=False):
     return rgb, ((a[..., 0] * 9797 + a[..., 1] * 19234 + a[..., 2] * 3737) >> 15).astype(np.uint8)
 
 
-def decode_file_ycc(source):
+def _pil_pixels_zero_copy(pil):
+    """``uint8 [H,W,4]`` view of a loaded 3-band PIL image's own storage (4 bytes per pixel), or None when this Pillow / pyarrow cannot
+    export it (older Pillow, image held in several memory blocks, pyarrow absent).  The view keeps the image alive."""
+    try:
+        import pyarrow as pa
+
+        pil.load()
+        arr = pa.array(pil)                                          # Image.__arrow_c_array__: fixed_size_list<uint8>[4], no copy
+        v = arr.values.to_numpy(zero_copy_only=True)
+        W, H = pil.size
+        return v.reshape(H, W, 4) if v.size == H * W * 4 and v.dtype == np.uint8 else None
+    except Exception:
+        return None
+
+
+def decode_file_ycc(source, padded=False):
     """A YCbCr-coded JPEG (JFIF, or Adobe marker with transform 1) decoded ONCE into libjpeg's YCbCr triples, ``uint8 [H,W,3]``; ``None``
     for every other file (callers fall back to ``decode_file``).  The two planes upstream's path branch reads are both functions of this
     one decode: the Y channel is ``cv2.imread(path, IMREAD_GRAYSCALE)``'s plane, and the RGB image is libjpeg's pointwise
     ``ycc_rgb_convert`` of the triple, which the device applies (``bbocr_op_ycc_to_rgb``) -- half the host's decode work of
-    ``decode_file`` (8.9 -> 4.6 ms of one core for a 1280x960 page) and no second pass over the file.  ``source``: path or bytes."""
+    ``decode_file`` (8.9 -> 4.6 ms of one core for a 1280x960 page) and no second pass over the file.  ``source``: path or bytes.
+
+    ``padded=True`` (decode pools): the result may be ``uint8 [H,W,4]`` -- Pillow's own pixel storage (Y Cb Cr x), exported without a copy
+    through the Arrow C data interface (Pillow >= 11.2 + pyarrow) -- instead of the tight ``[H,W,3]`` that ``tobytes`` assembles while holding
+    the interpreter lock (1.3 ms per page: with eight decode threads that serialised copy was what bounded the pool)."""
     from PIL import Image
 
     try:
@@ -115,6 +134,10 @@ def decode_file_ycc(source):
         pil.draft("YCbCr", size)
         if pil.mode != "YCbCr" or pil.size != size:
             return None
+        if padded:
+            v = _pil_pixels_zero_copy(pil)
+            if v is not None:
+                return v
         ycc = np.asarray(pil)
         if ycc.ndim != 3 or ycc.shape[2] != 3 or ycc.dtype != np.uint8:
             return None
@@ -397,14 +420,16 @@ class Reader:
         ``np.stack``: for 64 decoded pages that copy is 236 MB on one thread, the largest serial cost of a decode-bound caller)."""
         torch = self._torch
         if isinstance(arr, (list, tuple)):
-            first = np.asarray(arr[0])
-            t = torch.empty((len(arr),) + first.shape, dtype=torch.uint8, device=self.device)
-            for k, a in enumerate(arr):
-                a = np.ascontiguousarray(a)
-                if a.dtype != np.uint8 or a.shape != first.shape:
-                    raise ValueError("pages of one batch must be uint8 arrays of one shape")
-                t[k].copy_(_as_tensor(torch, a))
+            pages = [np.ascontiguousarray(a) for a in arr]           # (kept alive until the call below has returned)
+            first = pages[0]
+            if any(a.dtype != np.uint8 or a.shape != first.shape for a in pages):
+                raise ValueError("pages of one batch must be uint8 arrays of one shape")
+            t = torch.empty((len(pages),) + first.shape, dtype=torch.uint8, device=self.device)
             torch.cuda.current_stream(self.device_index).synchronize()
+            ptrs = (C.c_void_p * len(pages))(*[a.ctypes.data for a in pages])
+            # ONE call for the whole batch: the interpreter lock is released once, not once per page (with a decode pool running, every
+            # re-acquisition can wait for a thread that holds it)
+            self._check(self._lib.bbocr_upload_pages(self._h, ptrs, len(pages), first.nbytes, C.c_void_p(t.data_ptr())))
             return t
         arr = np.ascontiguousarray(arr)
         t = _as_tensor(torch, arr).to(self.device)
@@ -500,13 +525,13 @@ class Reader:
         planes ``readtext_device`` takes, computed on the card by libjpeg's own integer colour conversion."""
         self._dev_u8(ycc_dev, "ycc", 4)
         B, H, W, ch = ycc_dev.shape
-        if ch != 3:
-            raise ValueError(f"ycc: last dimension must be 3, got {ch}")
+        if ch not in (3, 4):                                         # 4: Pillow's padded pixels (decode_file_ycc(padded=True))
+            raise ValueError(f"ycc: last dimension must be 3 or 4, got {ch}")
         torch = self._torch
-        rgb = torch.empty_like(ycc_dev)
+        rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device=ycc_dev.device)
         gray = torch.empty((B, H, W), dtype=torch.uint8, device=ycc_dev.device)
         torch.cuda.current_stream(self.device_index).synchronize()       # the library runs on its own stream
-        self._check(self._lib.bbocr_op_ycc_to_rgb(self._h, C.c_void_p(ycc_dev.data_ptr()), B * H * W, C.c_void_p(rgb.data_ptr()),
+        self._check(self._lib.bbocr_op_ycc_to_rgb(self._h, C.c_void_p(ycc_dev.data_ptr()), B * H * W, ch, C.c_void_p(rgb.data_ptr()),
                                                   C.c_void_p(gray.data_ptr())))
         return rgb, gray
 
@@ -515,8 +540,8 @@ class Reader:
         ``readtext_arrays(rgb, gray)`` of the same files decoded twice."""
         if not isinstance(ycc, (list, tuple)):               # a list of [H,W,3] pages is uploaded page by page (Reader._to_dev)
             ycc = np.asarray(ycc)
-            if ycc.dtype != np.uint8 or ycc.ndim != 4 or ycc.shape[3] != 3:
-                raise ValueError("readtext_ycc_arrays expects uint8 [B,H,W,3]")
+            if ycc.dtype != np.uint8 or ycc.ndim != 4 or ycc.shape[3] not in (3, 4):
+                raise ValueError("readtext_ycc_arrays expects uint8 [B,H,W,3] (or [B,H,W,4]: Pillow's padded pixels)")
         rgb, gray = self.pages_from_ycc(self._to_dev(ycc))
         return self.readtext_device(rgb, gray, **kw)
 

@@ -254,7 +254,12 @@ int bbocr_op_resize_u8(bbocr_ctx* ctx, const uint8_t* dev_src, int N, int sh, in
  * (device) -> the RGB image libjpeg's own ycc_rgb_convert yields (what skimage / cv2.imread hand easyocr.utils.reformat_input,
  * reader.readtext at enhanced_extractor.py:520) and, when dev_gray is not NULL, the Y plane = cv2.imread(IMREAD_GRAYSCALE)'s
  * plane; both bit for bit (tests/test_oracle_cpu.py pins the formula against the decoder) */
-int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, uint8_t* dev_rgb, uint8_t* dev_gray);
+int bbocr_op_ycc_to_rgb(bbocr_ctx* ctx, const uint8_t* dev_ycc, size_t npix, int pixel_stride, uint8_t* dev_rgb, uint8_t* dev_gray);
+/* n separately allocated host pages of bytes_each bytes (the arrays a decode pool returns) -> one device buffer [n][bytes_each], copied
+ * inside ONE call: a Python host releases its interpreter lock once per batch instead of once per page, and needs no host-side
+ * concatenation of the pages (236 MB for 64 pages of 1280x960).  pixel_stride above: 3 = tight triples, 4 = Pillow's own 4-byte pixel
+ * storage (Y Cb Cr x) uploaded as it is. */
+int bbocr_upload_pages(bbocr_ctx* ctx, const void* const* host_pages, int n, size_t bytes_each, void* dev_dst);
 /* recogniser inputs for explicit boxes of ONE gray page: fills crops bf16 [n,64,imgW] (in box order); returns their count in *n_out.
  * contrast != 0 applies adjust_contrast_grey first.  mode 0: the boxes whose own padded width is imgW (Reader.recognize's per-box
  * branch); mode 1..4: EVERY box at the forced width imgW, rotated by np.rot90(crop, mode - 1) (the batched branch rotation_info takes) */

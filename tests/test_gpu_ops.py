@@ -132,8 +132,18 @@ def test_jpeg_colour_conversion_on_device_is_libjpegs(reader):
     rgb, gray = reader.pages_from_ycc(torch.from_numpy(np.ascontiguousarray(ycc)).cuda())
     assert np.array_equal(gray.cpu().numpy(), ycc[..., 0])
     assert np.array_equal(rgb.cpu().numpy(), imgproc.jpeg_ycc_to_rgb(ycc))
+    # Pillow's padded pixels (Y Cb Cr x): the fourth byte is ignored; pages handed over as a LIST reach the card through bbocr_upload_pages
+    rng = np.random.default_rng(2)
+    tight = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    padded = np.concatenate([tight, rng.integers(0, 256, (3, 37, 53, 1), dtype=np.uint8)], axis=-1)
+    rgb4, gray4 = reader.pages_from_ycc(reader._to_dev([padded[k] for k in range(3)]))
+    assert np.array_equal(rgb4.cpu().numpy(), imgproc.jpeg_ycc_to_rgb(tight)) and np.array_equal(gray4.cpu().numpy(), tight[..., 0])
+    ro = [np.frombuffer(tight[k].tobytes(), dtype=np.uint8).reshape(37, 53, 3) for k in range(3)]          # read-only pages, as PIL hands them out
+    assert np.array_equal(reader._to_dev(ro).cpu().numpy(), tight)
     with pytest.raises(ValueError):
-        reader.pages_from_ycc(torch.zeros((1, 4, 4, 4), dtype=torch.uint8, device="cuda"))
+        reader.pages_from_ycc(torch.zeros((1, 4, 4, 5), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        reader._to_dev([tight[0], tight[1, :20]])
 
 
 def test_ctc_matches_oracle(reader):
