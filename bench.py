@@ -296,7 +296,7 @@ def leg_host_pages(reader, pages, batch, steps, resident_value, in_flight=2):
             "boxes_per_step": nb / steps, "leg_seconds": time.perf_counter() - t_leg}
 
 
-def leg_extractor(reader, pages, n=512):
+def leg_extractor(reader, pages, n=1024):
     """SURVEY section 8 row f3, the application's own loop: a directory of JPEG files -> extractor_batch.extract_texts -> {index: text}
     (file read + JPEG decode on the host pool + H2D + the whole OCR path + the joined strings of enhanced_extractor.py:521) -- everything
     the reference's per-page loop at :680-688 does for its OCR step, batched.  PCIe- and decode-inclusive, never the headline value."""
