@@ -70,23 +70,39 @@ def ocr_input_image(image_path, image_index=None):
 def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, decode_workers=None, decode_once=True, **readtext_kw):
     """``{index: text}`` for every index of ``ocr_image_indices`` (default: all pages), text = ``" ".join(r[1] for r in results)``
     exactly as :521; a page whose OCR fails gets ``""`` like :529-531.  Pages of equal (down-scaled) shape travel in one device
-    batch of at most ``max_batch`` pages.
+    batch of at most ``max_batch`` pages (``read_files`` with the reference's OCR-input rule as the decode step)."""
+    res = read_files(reader, image_paths, ocr_image_indices, max_batch, decode_workers,
+                     decode=lambda path, i: _ocr_input(path, i, decode_once), **readtext_kw)
+    return {i: " ".join(t[1] for t in r) for i, r in res.items()}
+
+
+def _plain_input(path, i=None):
+    """Decode step of ``read_files`` without the extractor's thumbnail rule: what ``Reader.readtext(path)`` would hold."""
+    from .reader import decode_file_ycc, reformat_input
+
+    ycc = decode_file_ycc(os.fspath(path), padded=True)
+    return ("ycc", ycc, None) if ycc is not None else ("rgb",) + tuple(reformat_input(os.fspath(path)))
+
+
+def read_files(reader, image_paths, indices=None, max_batch=64, decode_workers=None, decode=_plain_input, **readtext_kw):
+    """``{index: readtext result}`` for the files ``image_paths[i]``, i in ``indices`` (default: all): the result lists
+    ``Reader.readtext(path)`` returns page by page, from 64-page device batches.  A page whose decode or OCR fails maps to ``[]``.
 
     Decoding (and the thumbnail + JPEG round trip) is what bounds the application once the OCR itself runs at hundreds of pages
     per second: a 1280x960 JPEG costs ~9 ms of one core decoded twice (RGB and the Y plane), ~4.6 ms decoded once into YCbCr triples
     (reader.decode_file_ycc: both planes are then derived on the card).  The files are therefore decoded by ``decode_workers`` threads (default:
     the host's cores, at most 16; PIL releases the GIL while decoding) and a shape group is sent to the device as soon as it is
     full, so the decode of later pages overlaps the device batch of earlier ones (ctypes releases the GIL during the C call).
-    ``decode_once=False`` keeps the two-pass decode (RGB, then the Y plane) for JPEG pages: same results, for A/B timing."""
+    ``decode(path, index)`` returns ``("ycc", triples, None)`` or ``("rgb", rgb, gray)``."""
     import collections
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
 
-    if ocr_image_indices is None:
-        ocr_image_indices = range(len(image_paths))
-    idxs = [i for i in ocr_image_indices if 0 <= i < len(image_paths)]
-    texts = {i: "" for i in idxs}
+    if indices is None:
+        indices = range(len(image_paths))
+    idxs = [i for i in indices if 0 <= i < len(image_paths)]
+    texts = {i: [] for i in idxs}
     if not idxs:
         return texts
     if decode_workers is None:
@@ -106,9 +122,9 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
     window = max(2 * max_batch, 2 * decode_workers)
     slots = threading.Semaphore(window)
 
-    def decode(i):
+    def decode_one(i):
         try:
-            return _ocr_input(image_paths[i], i, decode_once)
+            return decode(image_paths[i], i)
         except Exception:
             return None
 
@@ -134,7 +150,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
                             slots.release()
                             done_submitting = True
                             break
-                        pending.append((i, pool.submit(decode, i)))
+                        pending.append((i, pool.submit(decode_one, i)))
                     if not pending:
                         continue
                     i, fut = pending.popleft()
@@ -187,7 +203,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
                 else:
                     res = reader.readtext_device(rgb_dev, gray_dev, **readtext_kw)
                 for i, r in zip(ids, res):
-                    texts[i] = " ".join(t[1] for t in r)
+                    texts[i] = r
                 return
             except Exception:
                 pass
@@ -206,7 +222,7 @@ def extract_texts(reader, image_paths, ocr_image_indices=None, max_batch=64, dec
                 except Exception:
                     res.append([])
         for i, r in zip(ids, res):
-            texts[i] = " ".join(t[1] for t in r)
+            texts[i] = r
 
     worker = threading.Thread(target=assemble, daemon=True)
     worker.start()

@@ -611,6 +611,16 @@ class Reader:
                     out[i] = format_output(r, output_format, kw.get("paragraph", False), kw.get("detail", 1))
         return out
 
+    def readtext_files(self, paths, max_batch=64, decode_workers=None, **kw):
+        """Image FILES in, ``Reader.readtext(path)``'s result per file out (same order), through the decode pool / upload stage / two device
+        batches in flight of ``extractor_batch.read_files``: JPEG files are decoded once (YCbCr triples), pages of one size share device
+        batches.  A file that cannot be decoded or read maps to ``[]``."""
+        from .extractor_batch import read_files
+
+        paths = list(paths)
+        res = read_files(self, paths, None, max_batch, decode_workers, **kw)
+        return [res[i] for i in range(len(paths))]
+
     def readtext_arrays(self, rgb, gray=None, **kw):
         """Host arrays ``uint8 [B,H,W,3]`` (+ optional ``[B,H,W]`` gray planes, else derived on device) -> per-page results."""
         if isinstance(rgb, (list, tuple)):                   # lists of [H,W,3] (+ [H,W]) pages: uploaded page by page (Reader._to_dev)

@@ -492,6 +492,10 @@ def test_extractor_batching_and_tesseract_shim(reader, tmp_path):
     texts = eb.extract_texts(reader, paths)
     for i, p in enumerate(paths):
         assert texts[i] == " ".join(r[1] for r in reader.readtext(str(p))) and texts[i]
+    # Reader.readtext_files: the same pipeline without the extractor's thumbnail rule -- readtext(path)'s result per file, in order
+    files = [str(p) for p in paths] + [str(tmp_path / "missing.jpg")]
+    per_file = reader.readtext_files(files)
+    assert per_file[:-1] == [reader.readtext(f) for f in files[:-1]] and per_file[-1] == []
     from bb_ocr_amd.reader import decode_file, decode_file_ycc
     a, g = decode_file(str(paths[4]))
     want = reader.readtext_arrays(a[None], g[None])
