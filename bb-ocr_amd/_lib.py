@@ -18,7 +18,7 @@ class bbocr_config(C.Structure):
                 ("host_threads", C.c_int), ("reserved", C.c_int * 2)]
 
 
-PRECISIONS = {"bf16": 0, "fp16": 1, "exact": 2, "mixed": 3}
+PRECISIONS = {"bf16": 0, "fp16": 1, "exact": 2, "mixed": 3, "exact_rec": 4}
 
 
 class bbocr_tensor_desc(C.Structure):

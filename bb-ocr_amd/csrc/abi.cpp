@@ -31,7 +31,7 @@ int bbocr_create(const bbocr_config* cfg, bbocr_ctx** out) {
         c = new bbocr_ctx();
         c->root = c;
         if (cfg) c->cfg = *cfg;
-        if (c->cfg.precision < BBOCR_PREC_BF16 || c->cfg.precision > BBOCR_PREC_MIXED || c->cfg.call_slots < 0 || c->cfg.call_slots > kMaxSlots) {
+        if (c->cfg.precision < BBOCR_PREC_BF16 || c->cfg.precision > BBOCR_PREC_EXACT_REC || c->cfg.call_slots < 0 || c->cfg.call_slots > kMaxSlots) {
             delete c;                      // an unknown value must not silently mean one of the modes
             return BBOCR_ERR_ARG;
         }

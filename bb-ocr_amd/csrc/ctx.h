@@ -204,9 +204,9 @@ struct bbocr_ctx : WeightView {
 };
 
 // element type of a network's MFMA operands / stored activations (El<> in common.h), from bbocr_config::precision
-inline int det_el(const bbocr_ctx* c) { return (c->cfg.precision == BBOCR_PREC_FP16 || c->cfg.precision == BBOCR_PREC_EXACT) ? 1 : 0; }
+inline int det_el(const bbocr_ctx* c) { return (c->cfg.precision == BBOCR_PREC_FP16 || c->cfg.precision == BBOCR_PREC_EXACT || c->cfg.precision == BBOCR_PREC_EXACT_REC) ? 1 : 0; }
 inline int rec_el(const bbocr_ctx* c) { return c->cfg.precision != BBOCR_PREC_BF16 ? 1 : 0; }     // MIXED: bf16 detector, fp16 recogniser
-inline bool rec_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT; }   // recogniser tensors are [hi | lo] fp16 pairs
+inline bool rec_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT || c->cfg.precision == BBOCR_PREC_EXACT_REC; }   // recogniser tensors are [hi | lo] fp16 pairs
 inline bool det_split(const bbocr_ctx* c) { return c->cfg.precision == BBOCR_PREC_EXACT; }   // and so are the detector's (split-fp16 plans in every layer)
 
 // ------------------------------------------------------------------------------------------------ shared types

@@ -57,7 +57,8 @@ CONFIGS = {   # BASELINE.json configs -> (page W, H, batch per GPU, text lines, 
 TRAINED_CRNN = os.path.join(ROOT, "tests", "golden", "crnn_synth_fp16.npz")
 METRIC = {"p1": "book-page images/sec end-to-end (detect+recognize) @1280x960",
           "a4": "A4@300dpi page images/sec end-to-end (detect+recognize) @2480x3504, fp16 MFMA conv path (BASELINE.json configs[4], per-GPU share)"}
-DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands, three MFMA product terms per layer, in both networks)", "mixed": "bf16 (detector) + fp16 (recogniser)"}
+DTYPE = {"bf16": "bf16", "fp16": "fp16", "exact": "fp16 (split hi+lo operands, three MFMA product terms per layer, in both networks)", "mixed": "bf16 (detector) + fp16 (recogniser)",
+         "exact_rec": "fp16 (detector) + split fp16 hi+lo operands (recogniser)"}
 
 
 def log(msg, rank=0):
@@ -418,11 +419,11 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lines", type=int, default=0, help="text lines per page (0 = the config's: 24 / 110, SURVEY.md section 8d)")
-    ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed"), default=None, help="bbocr_config::precision (default: the config's)")
+    ap.add_argument("--precision", choices=("bf16", "fp16", "exact", "mixed", "exact_rec"), default=None, help="bbocr_config::precision (default: the config's)")
     ap.add_argument("--rec-weights", choices=("trained", "random"), default="trained", help="recogniser: tests/golden/crnn_synth_fp16.npz or seeded random")
     ap.add_argument("--cpu-pages", type=int, default=16, help="pages for the CPU-oracle baseline + parity_in_run after one warm-up page (0 = skip)")
-    ap.add_argument("--legs", default="serial,mixed,exact,a4,det_only,single_page,host_pages,lowconf,preprocess,extractor",
-                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, a4, det_only, single_page, host_pages, lowconf, preprocess, extractor; '' = none)")
+    ap.add_argument("--legs", default="serial,mixed,exact,exact_rec,a4,det_only,single_page,host_pages,lowconf,preprocess,extractor",
+                    help="N=1: extra legs run after the timed region (comma list of serial, fp16, mixed, bf16, exact, exact_rec, a4, det_only, single_page, host_pages, lowconf, preprocess, extractor; '' = none)")
     ap.add_argument("--leg-steps", type=int, default=6)
     ap.add_argument("--in-flight", type=int, default=2, help="calls in flight on the one Reader during the timed region (worker threads; bbocr_config::call_slots = 2)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
@@ -608,7 +609,7 @@ def main():
         del reader
         torch.cuda.empty_cache()
         for name in names:
-            if name in ("exact", "mixed", "fp16", "bf16") and not (args.config == "p1" and args.precision == name):
+            if name in ("exact", "mixed", "fp16", "bf16", "exact_rec") and not (args.config == "p1" and args.precision == name):
                 legs[name] = run_leg(name, "p1", name, args.leg_steps, (cs, rs), uniq if same else None, args.in_flight)
             elif name == "serial":
                 legs["serial"] = run_leg("serial", "p1", args.precision, args.leg_steps, (cs, rs), uniq if same else None, 1)

@@ -49,15 +49,17 @@ typedef struct bbocr_config {
                          *                        range 6e-8 .. 65504 -- BASELINE.json configs[4] ("fp16 MFMA conv path"), and what the Python host
                          *                        (bb_ocr_amd.Reader) selects unless told otherwise: boxes and strings equal to the fp32 CPU path's
                          *                        on every input class measured;
-                         *   BBOCR_PREC_EXACT (2) detector as FP16; recogniser in split fp16: every activation and weight is a pair
-                         *                        hi + lo of fp16 values (22 significand bits) and every product runs as the three MFMA
-                         *                        terms hi*hi + lo*hi + hi*lo accumulated in fp32, LSTM state and gates in fp32 --
-                         *                        additionally reproduces the CONFIDENCES of the fp32 CPU path (1e-5; 3x the recogniser's MFMA work);
+                         *   BBOCR_PREC_EXACT (2) BOTH networks in split fp16: every activation and weight is a pair hi + lo of fp16 values
+                         *                        (22 significand bits) and every product runs as the three MFMA terms hi*hi + lo*hi + hi*lo
+                         *                        accumulated in fp32, LSTM state and gates in fp32 -- threshold decisions and boxes follow the
+                         *                        fp32 CPU path on arbitrary heat-maps, CONFIDENCES to 1e-5 (3x the MFMA work: ~0.3x FP16's rate);
                          *   BBOCR_PREC_MIXED (3) detector as BF16, recogniser as FP16: 1.6 % faster than FP16 and as exact on binary-ink pages
                          *                        (2,051 of 2,051 boxes and strings of the 1280x960 workload equal the fp32 CPU path's,
                          *                        profiles/r03_text_parity.json): bf16 keeps the detector's clock (fp16 operands
                          *                        toggle more bits under the power limit); on continuous-tone images its bf16
                          *                        heat-map flips a few threshold decisions (3 of 110 boxes on the reference's images).
+                         *   BBOCR_PREC_EXACT_REC (4) detector as FP16, recogniser as in EXACT: the fp32 path's confidences (1e-5) -- what upstream's
+                         *                        contrast-retry decision and "keep the better pass" read -- at ~0.65x FP16's rate; boxes as FP16's.
                          * Any other value: bbocr_create returns BBOCR_ERR_ARG. */
     int call_slots;     /* calls that may be IN FLIGHT on this context at once: 0 = default (2), 1 = calls serialise (rounds 1-3), 2.
                          * The reference shares one Reader between ThreadPoolExecutor workers (batch_processor_enhanced.py:215, default 2).
@@ -71,7 +73,7 @@ typedef struct bbocr_config {
                          * share / LOCAL_WORLD_SIZE).  The pool is created once per slot and kept; no thread is spawned per call. */
     int reserved[2];
 } bbocr_config;
-enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2, BBOCR_PREC_MIXED = 3 };
+enum { BBOCR_PREC_BF16 = 0, BBOCR_PREC_FP16 = 1, BBOCR_PREC_EXACT = 2, BBOCR_PREC_MIXED = 3, BBOCR_PREC_EXACT_REC = 4 };
 
 /* One tensor of an upstream state-dict (easyocr/craft.py::CRAFT or easyocr/model/vgg_model.py::Model key names,
  * optional "module." prefix), fp32, host memory, C-contiguous.  Replaces torch.load + load_state_dict in

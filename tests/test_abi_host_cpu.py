@@ -69,11 +69,11 @@ def test_errors_are_status_codes_not_aborts(lib):
         cfg = _lib.bbocr_config(device=0)
         assert lib.bbocr_create(C.byref(cfg), C.byref(h)) == -2 and not h.value       # no HIP device: status, no crash
     # an unknown precision must not silently mean one of the modes: refused before anything touches a device
-    for bad in (-1, 4, 99):
+    for bad in (-1, 5, 99):
         h = C.c_void_p()
         cfg = _lib.bbocr_config(device=0, precision=bad)
         assert lib.bbocr_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
-    assert sorted(_lib.PRECISIONS.values()) == [0, 1, 2, 3]                          # bf16, fp16, exact, mixed (include/bbocr.h)
+    assert sorted(_lib.PRECISIONS.values()) == [0, 1, 2, 3, 4]                       # bf16, fp16, exact, mixed, exact_rec (include/bbocr.h)
 
 
 def _components_from_heat(text, link, low_text=0.4, link_thr=0.4, text_thr=0.7):

@@ -27,7 +27,7 @@ def test_configs_name_the_baseline_workloads():
 
     assert bench.CONFIGS["p1"][:3] == (1280, 960, 64) and "configs[2]" in bench.CONFIGS["p1"][6]
     assert bench.CONFIGS["a4"][:3] == (2480, 3504, 16) and bench.CONFIGS["a4"][5] == "fp16" and "configs[4]" in bench.CONFIGS["a4"][6]
-    assert set(bench.DTYPE) == {"bf16", "fp16", "exact", "mixed"} and bench.PEAK_BF16_TFLOPS == 2500.0
+    assert set(bench.DTYPE) == {"bf16", "fp16", "exact", "mixed", "exact_rec"} and bench.PEAK_BF16_TFLOPS == 2500.0
     assert abs(bench.CRAFT_GFLOP_PER_PAGE["p1"] - 874.22) < 1e-9 and abs(bench.CRAFT_GFLOP_PER_PAGE["a4"] - 3322.03) < 1e-9
 
 

@@ -15,14 +15,14 @@ from conftest import TRAINED_CRNN
 
 # boxes (of the full-page test below) whose decoded text may differ from the oracle's, per mode.  0 for the benchmarked default and for
 # `exact`; tools/parity_sweep.py measured the others on 2,000+ boxes (profiles/r03_text_parity.json).
-MAX_TEXT_MISMATCH = {"bf16": 1, "mixed": 0, "fp16": 0, "exact": 0}      # sweep: bf16 1 of 2,051; mixed / fp16 / exact 0 of 2,051
+MAX_TEXT_MISMATCH = {"bf16": 1, "mixed": 0, "fp16": 0, "exact": 0, "exact_rec": 0}      # sweep: bf16 1 of 2,051; mixed / fp16 / exact 0 of 2,051
 # relative confidence error on boxes whose text agrees (max, median).  The confidence is custom_mean = prod(p_t over the non-blank steps)
 # ** (2 / sqrt(n)): ONE arg-max flip at a blank <-> character transition (p ~ 0.5 on both sides; the text does not change) adds or
 # removes a factor ~0.5 ** (2 / sqrt(n)) -- 18 % on a 50-step line, more on short words -- so only `exact` reproduces it closely
-CONF_BOUND = {"bf16": (1.0, 0.02), "mixed": (0.3, 0.004), "fp16": (0.3, 0.004), "exact": (1e-3, 1e-4)}
+CONF_BOUND = {"bf16": (1.0, 0.02), "mixed": (0.3, 0.004), "fp16": (0.3, 0.004), "exact": (1e-3, 1e-4), "exact_rec": (1e-3, 1e-4)}
 # per time step: an arg-max may differ from the oracle's only where the ORACLE's own top-2 margin at THAT step (relative to the largest
 # |logit| of the crop) is below the mode's logit noise (compare per time step, not per box)
-STEP_MARGIN_BOUND = {"bf16": 6e-2, "mixed": 8e-3, "fp16": 8e-3, "exact": 1e-4}
+STEP_MARGIN_BOUND = {"bf16": 6e-2, "mixed": 8e-3, "fp16": 8e-3, "exact": 1e-4, "exact_rec": 1e-4}
 
 
 def _bench_pages(n, first=0):
@@ -61,7 +61,7 @@ def test_text_and_boxes_identical_on_full_size_pages(readers_trained, oracle_tra
     assert n_boxes >= 100
     rgb = torch.from_numpy(np.stack([p[0] for p in pages])).cuda()
     report = {}
-    for mode in ("bf16", "mixed", "fp16", "exact"):
+    for mode in ("bf16", "mixed", "fp16", "exact", "exact_rec"):      # exact_rec: fp16 detector + split-fp16 recogniser (confidences as exact's)
         got = readers_trained[mode].readtext_device(rgb)
         bad_text, conf_err = [], []
         for pw, pg in zip(want, got):
@@ -102,7 +102,8 @@ def test_argmax_flips_only_where_the_oracle_margin_is_below_the_noise(readers_tr
         steps += margin.size
         g = np.rint((x * 0.5 + 0.5) * 255.0).astype(np.int32)                            # the uint8 levels back (exact: x came from them)
         inputs = {"bf16": torch.from_numpy(x).to(torch.bfloat16), "mixed": torch.from_numpy(x).to(torch.float16),
-                  "fp16": torch.from_numpy(x).to(torch.float16), "exact": torch.from_numpy((g + 1).astype(np.int16))}
+                  "fp16": torch.from_numpy(x).to(torch.float16), "exact": torch.from_numpy((g + 1).astype(np.int16)),
+                  "exact_rec": torch.from_numpy((g + 1).astype(np.int16))}
         for mode, t in inputs.items():
             r = readers_trained[mode]
             T = W // 4 - 1
@@ -116,7 +117,7 @@ def test_argmax_flips_only_where_the_oracle_margin_is_below_the_noise(readers_tr
             assert not (diff & (margin >= STEP_MARGIN_BOUND[mode])).any(), \
                 f"{mode}: arg-max differs at a step whose oracle margin is {margin[diff].max():.3e} >= {STEP_MARGIN_BOUND[mode]:.0e}"
     print(f"{steps} time steps; arg-max flips against the fp32 oracle per mode: {flips}")
-    assert flips["exact"] == 0
+    assert flips["exact"] == 0 and flips["exact_rec"] == 0
 
 
 @pytest.mark.gpu
