@@ -420,6 +420,8 @@ class Reader:
         ``np.stack``: for 64 decoded pages that copy is 236 MB on one thread, the largest serial cost of a decode-bound caller)."""
         torch = self._torch
         if isinstance(arr, (list, tuple)):
+            if not arr:
+                raise ValueError("empty page list")
             pages = [np.ascontiguousarray(a) for a in arr]           # (kept alive until the call below has returned)
             first = pages[0]
             if any(a.dtype != np.uint8 or a.shape != first.shape for a in pages):

@@ -320,7 +320,7 @@ def leg_extractor(reader, pages, n=1024):
         texts = extractor_batch.extract_texts(reader, paths)
         dt = time.perf_counter() - t0
     return {"what": f"{n} JPEG files (1280x960, quality 92) -> extractor_batch.extract_texts: decode pool (one YCbCr decode per page, RGB + Y plane "
-                    f"derived on the card), page-by-page H2D, two device batches in flight, joined strings",
+                    f"derived on the card), one upload call per batch a batch ahead, two device batches in flight, joined strings",
             "value": n / dt, "unit": "images/s", "pages": n, "non_empty_texts": sum(bool(t) for t in texts.values()), "host_cores": host_cores(),
             "leg_seconds": time.perf_counter() - t_leg}
 

@@ -144,6 +144,13 @@ def test_jpeg_colour_conversion_on_device_is_libjpegs(reader):
         reader.pages_from_ycc(torch.zeros((1, 4, 4, 5), dtype=torch.uint8, device="cuda"))
     with pytest.raises(ValueError):
         reader._to_dev([tight[0], tight[1, :20]])
+    with pytest.raises(ValueError):
+        reader._to_dev([])
+    import ctypes as C_
+    dst = torch.empty((2, 16), dtype=torch.uint8, device="cuda")
+    ptrs = (C_.c_void_p * 2)(tight[0].ctypes.data, None)                       # a null page: status code and message, no fault
+    assert reader._lib.bbocr_upload_pages(reader._h, ptrs, 2, 16, C_.c_void_p(dst.data_ptr())) == -1
+    assert b"null page" in reader._lib.bbocr_last_error(reader._h)
 
 
 def test_ctc_matches_oracle(reader):
