@@ -438,6 +438,12 @@ def test_extractor_downscale_rule_and_batching(tmp_path):
     fr2 = FakeReader()
     t2 = eb.extract_texts(fr2, many, max_batch=4, decode_workers=3)
     assert t2 == {i: "w400 x" for i in range(37)} and sum(b[0] for b in fr2.batches) == 37 and max(b[0] for b in fr2.batches) <= 4
+    # ... and a full group is what travels: pages that are still being decoded do not count as "held in partial groups" (round 3's
+    # assembler cut batches into single pages whenever the decode pool ran ahead: 387 device calls for 512 pages)
+    assert sorted(b[0] for b in fr2.batches) == [1] + [4] * 9
+    fr3 = FakeReader()
+    t3 = eb.extract_texts(fr3, [good] * 64, max_batch=8, decode_workers=8)
+    assert len(t3) == 64 and sorted(b[0] for b in fr3.batches) == [8] * 8
 
 
 def test_paragraph_and_ignore_mask_rules():
