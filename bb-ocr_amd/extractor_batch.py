@@ -106,13 +106,13 @@ def read_files(reader, image_paths, indices=None, max_batch=64, decode_workers=N
     if not idxs:
         return texts
     if decode_workers is None:
-        # a third of the process's CPU share (affinity mask and cgroup quota, bbocr_host_cpu_share), at most 8: the library's own host pool and
-        # the two device-call threads need the rest -- on a 16-CPU share 4-5 decode threads gave the steadiest rate, 8 and 16 a noisier one
+        # half of the process's CPU share (affinity mask and cgroup quota, bbocr_host_cpu_share), at most 8: the library's own host pool, the
+        # upload stage and the two device-call threads need the rest (16-CPU share: 4 threads 700-780 pages/s, 8: 720-790, 16: 755-825)
         try:
             share = int(reader._lib.bbocr_host_cpu_share())
         except Exception:
             share = os.cpu_count() or 1
-        decode_workers = max(1, min(8, share // 3, len(idxs)))
+        decode_workers = max(1, min(8, share // 2, len(idxs)))
 
     # three overlapped stages: decode pool -> assembler thread (groups pages by shape, hands a full group on as one batch)
     # -> this thread (device call + result strings).  Back-pressure end to end: at most `window` decoded pages exist outside the two
