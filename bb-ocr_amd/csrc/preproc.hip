@@ -72,9 +72,11 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_kernel(const uint8_t* __r
 // as whole dwords.  Float64 estimate (error < 1e-12) and the exact 128-bit decision within 1e-9 of a tie, like pp_resize_cubic_kernel:
 // the byte is fully determined by the mathematics, not by the order or fusing of the float operations.  Launched only when the window fits PP_RS_SW x PP_RS_SH (any scale >= ~0.55).
 #define PP_RS_TW 64
-#define PP_RS_TH 16
 #define PP_RS_SW 128
 #define PP_RS_SH 36
+// TH = output rows per tile: 32 where the window still fits PP_RS_SH rows (scales >= ~1.04: twice the work per workgroup behind the same
+// chain of table loads -> window loads -> two barriers, which is what a tile costs), else 16
+template <int TH>
 __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_t* __restrict__ src, int H, int W, uint8_t* __restrict__ dst, int dh,
                                                                      int dw, const int* __restrict__ x0, const double* __restrict__ wx,
                                                                      const long long* __restrict__ nx, const int* __restrict__ y0,
@@ -82,19 +84,20 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_
                                                                      unsigned long long KX, unsigned long long KY) {
     __shared__ uint8_t win[PP_RS_SH][PP_RS_SW];
     __shared__ double hor[PP_RS_SH][PP_RS_TW];
-    __shared__ uint8_t res[PP_RS_TH][PP_RS_TW];
-    const int ox = blockIdx.x * PP_RS_TW, oy = blockIdx.y * PP_RS_TH;
-    const int nxo = min(PP_RS_TW, dw - ox), nyo = min(PP_RS_TH, dh - oy);
-    // a thread keeps one output column (lx) and the output rows wv, wv+4, wv+8, wv+12 of the tile through both phases: its table entries
+    constexpr int NIT = TH / 4;
+    __shared__ uint8_t res[TH][PP_RS_TW];
+    const int ox = blockIdx.x * PP_RS_TW, oy = blockIdx.y * TH;
+    const int nxo = min(PP_RS_TW, dw - ox), nyo = min(TH, dh - oy);
+    // a thread keeps one output column (lx) and the output rows wv, wv+4, wv+8, ... of the tile through both phases: its table entries
     // are fetched up front, next to the window's corner taps, so the window load is the only dependent global access of the block
     const int lx = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dx = min(ox + lx, dw - 1);
     const int myx = x0[dx];
     const double w0 = wx[dx * 4], w1 = wx[dx * 4 + 1], w2 = wx[dx * 4 + 2], w3 = wx[dx * 4 + 3];
-    int myy[4];
-    double v[4][4];
+    int myy[NIT];
+    double v[NIT][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int dy = min(oy + wv + 4 * it, dh - 1);
         myy[it] = y0[dy];
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int ly = wv + 4 * it;
         if (ly >= nyo || lx >= nxo) continue;
         const int dy = oy + ly, ry = myy[it] - sy0;
@@ -151,10 +154,10 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_
     }
     __syncthreads();
     if (nxo == PP_RS_TW && (dw & 3) == 0 && ((size_t)dst & 3) == 0) {   // whole dwords, 16 lanes per output row
-        const int ly = threadIdx.x >> 4, q = threadIdx.x & 15;
-        if (ly < nyo) *(unsigned int*)(dst + (size_t)(oy + ly) * dw + ox + q * 4) = *(const unsigned int*)&res[ly][q * 4];
+        const int q = threadIdx.x & 15;
+        for (int ly = threadIdx.x >> 4; ly < nyo; ly += 16) *(unsigned int*)(dst + (size_t)(oy + ly) * dw + ox + q * 4) = *(const unsigned int*)&res[ly][q * 4];
     } else {
-        for (int i = threadIdx.x; i < PP_RS_TH * PP_RS_TW; i += 256) {
+        for (int i = threadIdx.x; i < TH * PP_RS_TW; i += 256) {
             const int ly = i >> 6, lx = i & 63;
             if (ly < nyo && lx < nxo) dst[(size_t)(oy + ly) * dw + ox + lx] = res[ly][lx];
         }
@@ -646,11 +649,16 @@ static inline int pp_grid(size_t total) {
 hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const double* wx, const long long* nx,
                                   const int* y0, const double* wy, const long long* ny, unsigned long long KX, unsigned long long KY, hipStream_t s) {
     // window of a 64 x 16 output tile: at most ceil(tile * src / dst) + 4 source columns / rows
-    const long long sw = ((long long)PP_RS_TW * W + dw - 1) / dw + 5, sh = ((long long)PP_RS_TH * H + dh - 1) / dh + 5;
-    const unsigned gy = (unsigned)((dh + PP_RS_TH - 1) / PP_RS_TH);
-    if (sw <= PP_RS_SW && sh <= PP_RS_SH && gy <= 65535u) {
-        hipLaunchKernelGGL(pp_resize_cubic_tiled_kernel, dim3((dw + PP_RS_TW - 1) / PP_RS_TW, gy), dim3(256), 0, s, src, H, W, dst, dh, dw, x0, wx,
-                           nx, y0, wy, ny, KX, KY);
+    const long long sw = ((long long)PP_RS_TW * W + dw - 1) / dw + 5;
+    const long long sh32 = (32LL * H + dh - 1) / dh + 5, sh16 = (16LL * H + dh - 1) / dh + 5;
+    if (sw <= PP_RS_SW && sh32 <= PP_RS_SH && (dh + 31) / 32 <= 65535) {
+        hipLaunchKernelGGL(pp_resize_cubic_tiled_kernel<32>, dim3((dw + PP_RS_TW - 1) / PP_RS_TW, (dh + 31) / 32), dim3(256), 0, s, src, H, W, dst, dh, dw,
+                           x0, wx, nx, y0, wy, ny, KX, KY);
+        return hipGetLastError();
+    }
+    if (sw <= PP_RS_SW && sh16 <= PP_RS_SH && (dh + 15) / 16 <= 65535) {
+        hipLaunchKernelGGL(pp_resize_cubic_tiled_kernel<16>, dim3((dw + PP_RS_TW - 1) / PP_RS_TW, (dh + 15) / 16), dim3(256), 0, s, src, H, W, dst, dh, dw,
+                           x0, wx, nx, y0, wy, ny, KX, KY);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(pp_resize_cubic_kernel, dim3(pp_grid((size_t)dh * dw)), dim3(256), 0, s, src, H, W, dst, dh, dw, x0, wx, nx, y0, wy, ny, KX, KY);
