@@ -397,34 +397,37 @@ __global__ void __launch_bounds__(256) pp_box0_x4_kernel(const uint8_t* __restri
 __device__ __forceinline__ unsigned int pp_box0(unsigned int v, unsigned int a, unsigned int b, unsigned int ww, unsigned int fw) {
     return ((v * ww + (a + b) * fw) + (1u << 23)) >> 24;
 }
+// the four pixels row[x .. x+3] after the three row passes (dword-aligned x, W % 4 == 0)
+__device__ __forceinline__ unsigned int pp_box0_h3_dw(const uint8_t* __restrict__ row, int x, int W, unsigned int ww, unsigned int fw) {
+    const bool first = x == 0, last = x + 4 == W;
+    const unsigned int c = *(const unsigned int*)(row + x);
+    const unsigned int l = first ? (c & 255u) * 0x01010101u : *(const unsigned int*)(row + x - 4);
+    const unsigned int r = last ? (c >> 24) * 0x01010101u : *(const unsigned int*)(row + x + 4);
+    unsigned int in[10], y1[8], y2[6];                           // positions x-3.., x-2.., x-1..
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in[k] = (l >> (8 * (k + 1))) & 255u; in[7 + k] = (r >> (8 * k)) & 255u; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) in[3 + k] = (c >> (8 * k)) & 255u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y1[k] = pp_box0(in[k + 1], in[k], in[k + 2], ww, fw);
+    if (first) y1[0] = y1[1] = y1[2];
+    if (last) y1[6] = y1[7] = y1[5];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y2[k] = pp_box0(y1[k + 1], y1[k], y1[k + 2], ww, fw);
+    if (first) y2[0] = y2[1];
+    if (last) y2[5] = y2[4];
+    unsigned int o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o |= pp_box0(y2[k + 1], y2[k], y2[k + 2], ww, fw) << (8 * k);
+    return o;
+}
 __global__ void __launch_bounds__(256) pp_box0_h3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W, unsigned int ww,
                                                           unsigned int fw) {
     const int W4 = W >> 2;
     const size_t total = (size_t)H * W4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int y = pp_row(i, W4), x = (int)(i - (size_t)y * W4) << 2;
-        const uint8_t* row = src + (size_t)y * W;
-        const bool first = x == 0, last = x + 4 == W;
-        const unsigned int c = *(const unsigned int*)(row + x);
-        const unsigned int l = first ? (c & 255u) * 0x01010101u : *(const unsigned int*)(row + x - 4);
-        const unsigned int r = last ? (c >> 24) * 0x01010101u : *(const unsigned int*)(row + x + 4);
-        unsigned int in[10], y1[8], y2[6];                       // positions x-3.., x-2.., x-1..
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { in[k] = (l >> (8 * (k + 1))) & 255u; in[7 + k] = (r >> (8 * k)) & 255u; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) in[3 + k] = (c >> (8 * k)) & 255u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) y1[k] = pp_box0(in[k + 1], in[k], in[k + 2], ww, fw);
-        if (first) y1[0] = y1[1] = y1[2];
-        if (last) y1[6] = y1[7] = y1[5];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) y2[k] = pp_box0(y1[k + 1], y1[k], y1[k + 2], ww, fw);
-        if (first) y2[0] = y2[1];
-        if (last) y2[5] = y2[4];
-        unsigned int o = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o |= pp_box0(y2[k + 1], y2[k], y2[k + 2], ww, fw) << (8 * k);
-        *(unsigned int*)(dst + (size_t)y * W + x) = o;
+        *(unsigned int*)(dst + (size_t)y * W + x) = pp_box0_h3_dw(src + (size_t)y * W, x, W, ww, fw);
     }
 }
 // ---- the three column passes of box radius 0 AND the UnsharpMask combine in one launch: a thread owns a dword column (four pixels
@@ -451,7 +454,9 @@ __device__ __forceinline__ unsigned int pp_unsharp_dw(unsigned int av, unsigned 
     }
     return ov;
 }
-template <int R>
+// HROWS: `blur_of` is the mask's INPUT and the three row passes are applied to each of the R + 6 rows as it is loaded (three dwords per
+// row, the neighbours' from the L1) -- the whole UnsharpMask in one launch, no intermediate plane.
+template <int R, bool HROWS>
 __global__ void __launch_bounds__(256) pp_box0_v3_unsharp_kernel(const uint8_t* __restrict__ blur_of, const uint8_t* __restrict__ in,
                                                                   uint8_t* __restrict__ dst, int H, int W, unsigned int ww, unsigned int fw,
                                                                   int percent, int threshold) {
@@ -464,7 +469,8 @@ __global__ void __launch_bounds__(256) pp_box0_v3_unsharp_kernel(const uint8_t* 
     for (int k = 0; k < R + 6; ++k) {
         int y = y0 - 3 + k;
         y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-        a[k] = *(const unsigned int*)(blur_of + (size_t)y * W + x);
+        if constexpr (HROWS) a[k] = pp_box0_h3_dw(blur_of + (size_t)y * W, x, W, ww, fw);
+        else a[k] = *(const unsigned int*)(blur_of + (size_t)y * W + x);
     }
     const bool top = y0 == 0, bottom = y0 + R + 2 > H - 1;       // block-uniform
     // level 1 at rows y0-2+k
@@ -710,11 +716,16 @@ bool pp_unsharp_fused_ok(int H, int W, int r, const uint8_t* a, const uint8_t* b
 }
 hipError_t launch_pp_unsharp_fused(const uint8_t* in, uint8_t* tmp, uint8_t* dst, int H, int W, unsigned int ww, unsigned int fw, int percent,
                                    int threshold, hipStream_t s) {
+    if (!tmp) {                                                  // one launch: row passes applied on the fly
+        hipLaunchKernelGGL((pp_box0_v3_unsharp_kernel<16, true>), dim3(((W >> 2) + 255) / 256, (H + 15) / 16), dim3(256), 0, s, in, in, dst, H, W, ww, fw,
+                           percent, threshold);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pp_box0_h3_kernel, dim3(pp_grid((size_t)H * (W >> 2))), dim3(256), 0, s, in, tmp, H, W, ww, fw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pp_box0_v3_unsharp_kernel<16>, dim3(((W >> 2) + 255) / 256, (H + 15) / 16), dim3(256), 0, s, tmp, in, dst, H, W, ww, fw, percent,
-                       threshold);
+    hipLaunchKernelGGL((pp_box0_v3_unsharp_kernel<16, false>), dim3(((W >> 2) + 255) / 256, (H + 15) / 16), dim3(256), 0, s, tmp, in, dst, H, W, ww, fw,
+                       percent, threshold);
     return hipGetLastError();
 }
 hipError_t launch_pp_unsharp(const uint8_t* in, const uint8_t* blur, uint8_t* dst, size_t total, int percent, int threshold, hipStream_t s) {

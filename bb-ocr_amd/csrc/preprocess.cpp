@@ -141,6 +141,7 @@ void pp_unsharp(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, ui
     const unsigned int ww = (unsigned int)((float)(1 << 24) / (fr * 2.f + 1.f));
     const unsigned int fw = ((1u << 24) - (unsigned int)(r * 2 + 1) * ww) / 2;
     if (pp_unsharp_fused_ok(H, W, r, src, tmp1, dst)) {       // the chain's own case (radius 1 -> box radius 0): 2 launches instead of 7
+        // (tmp = nullptr: the row passes applied on the fly inside the column kernel, ONE launch -- measured equal: 130 us against 67 + 63)
         HIPCHK(launch_pp_unsharp_fused(src, tmp1, dst, H, W, ww, fw, percent, threshold, c->stream));
         return;
     }
