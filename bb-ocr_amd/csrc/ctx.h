@@ -330,7 +330,7 @@ double percentile_u8(const unsigned int* hist, size_t n, double q);
 void rec_early_begin(bbocr_ctx* c, const uint8_t* gray, int pages, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, RecEarly& e);
 void recognize_impl(bbocr_ctx* c, const uint8_t* gray, int B, int H, int W, const HostBoxes& hb, const bbocr_params& p, std::vector<BoxJob>& jobs, std::vector<int>& box_off, RecEarly* early = nullptr);
 bbocr_result* export_result(int B, const std::vector<BoxJob>& jobs, const std::vector<int>& box_off);
-void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw);   // enqueues; the caller waits
+void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, bool src_bgr = false);   // enqueues; the caller waits
 void pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma);
 const uint8_t* pp_fold_lut(bbocr_ctx* c, size_t n, double contrast, double brightness);
 void pp_clahe(bbocr_ctx* c, const uint8_t* src, int H, int W, const uint8_t* d_lut, uint8_t* dst, double clip_limit);

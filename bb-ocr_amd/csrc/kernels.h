@@ -165,8 +165,9 @@ void ctc_beam_search_batch(const float* probs, const int* seqs, int nseq, int C,
                            HostPool* pool = nullptr);     // pool: the calling slot's workers (null: the calling thread alone)
 
 // ------------------------------------------------------------------ OCR pre-processing chain (preproc.hip), SURVEY 8 row f2
+int pp_resize_tile_rows(int H, int W, int dh, int dw);
 hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const double* wx, const long long* nx,
-                                  const int* y0, const double* wy, const long long* ny, unsigned long long KX, unsigned long long KY, hipStream_t s);
+                                  const int* y0, const double* wy, const long long* ny, unsigned long long KX, unsigned long long KY, hipStream_t s, int src_bgr = 0);
 hipError_t launch_pp_gauss3(const uint8_t* src, int H, int W, uint8_t* dst, int k0, int k1, int k2, unsigned long long* sum, hipStream_t s);
 hipError_t launch_pp_clahe_hist(const uint8_t* src, int H, int W, const uint8_t* lut, int tw, int th, int tx, int ty, unsigned int* hist,
                                 hipStream_t s);

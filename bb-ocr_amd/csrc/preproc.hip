@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_kernel(const uint8_t* __r
 #define PP_RS_SH 36
 // TH = output rows per tile: 32 where the window still fits PP_RS_SH rows (scales >= ~1.04: twice the work per workgroup behind the same
 // chain of table loads -> window loads -> two barriers, which is what a tile costs), else 16
-template <int TH>
+// BGR: `src` is the interleaved 3-channel page and the window is filled with its cv2 BGR2GRAY values (craft_misc.hip::gray_kernel's formula):
+// the chain's first stage rides in the window load, the gray plane of the source size is never written.
+template <int TH, bool BGR>
 __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_t* __restrict__ src, int H, int W, uint8_t* __restrict__ dst, int dh,
                                                                      int dw, const int* __restrict__ x0, const double* __restrict__ wx,
                                                                      const long long* __restrict__ nx, const int* __restrict__ y0,
@@ -108,11 +110,16 @@ __global__ void __launch_bounds__(256) pp_resize_cubic_tiled_kernel(const uint8_
     for (int ry = wv; ry < sh; ry += 4) {                          // window: a wave per row, lanes along it (no index division)
         int y = sy0 + ry;
         y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-        const uint8_t* row = src + (size_t)y * W;
+        const uint8_t* row = src + (size_t)y * W * (BGR ? 3 : 1);
         for (int rx = lx; rx < sw; rx += 64) {
             int x = sx0 + rx;
             x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-            win[ry][rx] = row[x];
+            if constexpr (BGR) {
+                const int c0 = row[x * 3], c1 = row[x * 3 + 1], c2 = row[x * 3 + 2];
+                win[ry][rx] = (uint8_t)((c2 * 9798 + c1 * 19235 + c0 * 3735 + (1 << 14)) >> 15);
+            } else {
+                win[ry][rx] = row[x];
+            }
         }
     }
     __syncthreads();
@@ -652,21 +659,32 @@ static inline int pp_grid(size_t total) {
     return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
-hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const double* wx, const long long* nx,
-                                  const int* y0, const double* wy, const long long* ny, unsigned long long KX, unsigned long long KY, hipStream_t s) {
-    // window of a 64 x 16 output tile: at most ceil(tile * src / dst) + 4 source columns / rows
+// which tile height the LDS-tiled kernel takes for this geometry (0: none fits, the per-pixel kernel runs)
+int pp_resize_tile_rows(int H, int W, int dh, int dw) {
     const long long sw = ((long long)PP_RS_TW * W + dw - 1) / dw + 5;
     const long long sh32 = (32LL * H + dh - 1) / dh + 5, sh16 = (16LL * H + dh - 1) / dh + 5;
-    if (sw <= PP_RS_SW && sh32 <= PP_RS_SH && (dh + 31) / 32 <= 65535) {
-        hipLaunchKernelGGL(pp_resize_cubic_tiled_kernel<32>, dim3((dw + PP_RS_TW - 1) / PP_RS_TW, (dh + 31) / 32), dim3(256), 0, s, src, H, W, dst, dh, dw,
-                           x0, wx, nx, y0, wy, ny, KX, KY);
+    if (sw <= PP_RS_SW && sh32 <= PP_RS_SH && (dh + 31) / 32 <= 65535) return 32;
+    if (sw <= PP_RS_SW && sh16 <= PP_RS_SH && (dh + 15) / 16 <= 65535) return 16;
+    return 0;
+}
+// src_bgr != 0: src is the interleaved 3-channel page (only where pp_resize_tile_rows() != 0)
+hipError_t launch_pp_resize_cubic(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, const int* x0, const double* wx, const long long* nx,
+                                  const int* y0, const double* wy, const long long* ny, unsigned long long KX, unsigned long long KY, hipStream_t s,
+                                  int src_bgr) {
+    // window of a 64 x 16 output tile: at most ceil(tile * src / dst) + 4 source columns / rows
+    const int th = pp_resize_tile_rows(H, W, dh, dw);
+    const dim3 grid((dw + PP_RS_TW - 1) / PP_RS_TW, th ? (dh + th - 1) / th : 1);
+#define PP_RS_LAUNCH(TH_, BGR_) hipLaunchKernelGGL((pp_resize_cubic_tiled_kernel<TH_, BGR_>), grid, dim3(256), 0, s, src, H, W, dst, dh, dw, x0, wx, nx, y0, wy, ny, KX, KY)
+    if (th == 32) {
+        if (src_bgr) PP_RS_LAUNCH(32, true); else PP_RS_LAUNCH(32, false);
         return hipGetLastError();
     }
-    if (sw <= PP_RS_SW && sh16 <= PP_RS_SH && (dh + 15) / 16 <= 65535) {
-        hipLaunchKernelGGL(pp_resize_cubic_tiled_kernel<16>, dim3((dw + PP_RS_TW - 1) / PP_RS_TW, (dh + 15) / 16), dim3(256), 0, s, src, H, W, dst, dh, dw,
-                           x0, wx, nx, y0, wy, ny, KX, KY);
+    if (th == 16) {
+        if (src_bgr) PP_RS_LAUNCH(16, true); else PP_RS_LAUNCH(16, false);
         return hipGetLastError();
     }
+#undef PP_RS_LAUNCH
+    if (src_bgr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pp_resize_cubic_kernel, dim3(pp_grid((size_t)dh * dw)), dim3(256), 0, s, src, H, W, dst, dh, dw, x0, wx, nx, y0, wy, ny, KX, KY);
     return hipGetLastError();
 }

@@ -63,7 +63,7 @@ static unsigned char* pp_tab(bbocr_ctx* c) {
 
 // Enqueues the resize; the weight tables stay on the device while the geometry repeats (one page size per batch is the rule), so
 // only a change of (W, dw, H, dh) costs their computation, six uploads and a wait.
-void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw) {
+void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, bool src_bgr) {
     const size_t nx = (size_t)dw, ny = (size_t)dh;
     const int key[4] = {W, dw, H, dh};
     const bool hit = c->pp_cubic.p && std::memcmp(key, c->pp_cubic_key, sizeof key) == 0;
@@ -93,7 +93,7 @@ void pp_resize(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int
         c->pp_cubic_K[1] = ay.K;
         std::memcpy(c->pp_cubic_key, key, sizeof key);
     }
-    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, c->pp_cubic_K[0], c->pp_cubic_K[1], c->stream));
+    HIPCHK(launch_pp_resize_cubic(src, H, W, dst, dh, dw, x0, wx, ix, y0, wy, iy, c->pp_cubic_K[0], c->pp_cubic_K[1], c->stream, src_bgr ? 1 : 0));
 }
 // GaussianBlur 3x3 (sigma <= 0: the identity taps); leaves the sum of the output pixels at PP_SUM for the following Contrast step.  Enqueues.
 void pp_gauss(bbocr_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, double sigma) {
@@ -163,13 +163,16 @@ void preprocess_chain_impl(bbocr_ctx* c, const uint8_t* bgr, int H, int W, const
     c->pp_b.ensure(n);
     c->pp_c.ensure(n);
     uint8_t *g = (uint8_t*)c->pp_gray.p, *bufs[3] = {(uint8_t*)c->pp_a.p, (uint8_t*)c->pp_b.p, (uint8_t*)c->pp_c.p};
-    HIPCHK(launch_gray(bgr, g, (size_t)H * W, c->stream));             // channels as given: B 3735, G 19235, R 9798 (>> 15) for cv2.imread's BGR
+    // channels as given: B 3735, G 19235, R 9798 (>> 15) for cv2.imread's BGR.  When the LDS-tiled resize follows, the conversion rides in its
+    // window load and the source-size gray plane is never written
+    const bool gray_in_resize = q.scale > 0 && pp_resize_tile_rows(H, W, dh, dw) != 0;
+    if (!gray_in_resize) HIPCHK(launch_gray(bgr, g, (size_t)H * W, c->stream));
     const uint8_t* cur = g;
     int nb = 0;                                                        // next free plane of the three
     auto next = [&]() { uint8_t* b = bufs[nb]; nb = (nb + 1) % 3; return b; };
     if (q.scale > 0) {
         uint8_t* d = next();
-        pp_resize(c, cur, H, W, d, dh, dw);
+        pp_resize(c, gray_in_resize ? bgr : cur, H, W, d, dh, dw, gray_in_resize);
         cur = d;
     }
     // the mean ImageEnhance.Contrast needs: the blur kernel sums its own output; without a blur stage the identity taps (0, 256, 0) do

@@ -274,7 +274,9 @@ def test_preprocess_chain_bit_exact_vs_oracle(reader):
     bgr = rng.integers(0, 256, (96, 144, 3), dtype=np.uint8)
     dev = torch.from_numpy(bgr).cuda()
     for kw in (dict(scale=0.0), dict(blur_sigma=0.0), dict(contrast=0.0, brightness=0.0), dict(clahe_clip=0.0), dict(unsharp_percent=0),
-               dict(blur_sigma=0.0, clahe_clip=0.0), dict(scale=0.0, blur_sigma=0.0, contrast=0.0, brightness=0.0, clahe_clip=0.0, unsharp_percent=0)):
+               dict(blur_sigma=0.0, clahe_clip=0.0), dict(scale=0.0, blur_sigma=0.0, contrast=0.0, brightness=0.0, clahe_clip=0.0, unsharp_percent=0),
+               # other scales: 1.02 / 0.8 -> 16-row resize tiles with the gray conversion in their window load, 0.3 -> gray plane + per-pixel resize
+               dict(scale=1.02), dict(scale=0.8), dict(scale=0.3, clahe_clip=0.0)):
         ref_kw = dict(scale=1.5, blur_sigma=3.0, contrast=1.9, brightness=1.2, clahe_clip=2.5, unsharp_percent=30)
         ref_kw.update(kw)
         assert np.array_equal(dev_pp.preprocess_bgr_device(reader, dev, **kw).cpu().numpy(), pp.preprocess_chain(bgr, **ref_kw)), kw
