@@ -4,8 +4,9 @@
 //   cv2 CLAHE (clip 2.5, 8x8 tiles) -> PIL UnsharpMask(radius 1, 30 %, threshold 3).
 // All stages are 8-bit integer / byte work on one channel, HBM-bound (one read + one write of the 1.5x-upscaled plane each);
 // the integer arithmetic is the CPU restatement's (oracle/preprocess.py) operation for operation, float steps are evaluated
-// in the same order without contraction (-ffp-contract=off).  Coefficient tables, the contrast/brightness LUT and the CLAHE
-// tile LUTs are tiny and are built on the host (api.cpp) from device-side sums / histograms.
+// in the same order without contraction (-ffp-contract=off).  The cubic coefficient tables are built on the host once per page
+// geometry (preprocess.cpp) and stay on the device; the contrast / brightness LUT and the CLAHE tile LUTs are built by one-block device
+// kernels from the device-resident sum / histograms, so the chain runs without a host round trip.
 #include "common.h"
 #include "kernels.h"
 
