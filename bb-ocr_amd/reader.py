@@ -607,7 +607,8 @@ class Reader:
         max_pages = int(os.environ.get("BBOCR_MAX_DEVICE_BATCH", "64"))     # pages per device batch; larger groups stream, two batches in flight
         for _, idxs in by_shape.items():
             chunks = [idxs[k:k + max_pages] for k in range(0, len(idxs), max_pages)]
-            feed = ((self._to_dev(np.stack([pages[i][0] for i in ch])), self._to_dev(np.stack([pages[i][1] for i in ch]))) for ch in chunks)
+            # (lists: the pages reach the card in one upload call per batch, without a host-side np.stack)
+            feed = ((self._to_dev([pages[i][0] for i in ch]), self._to_dev([pages[i][1] for i in ch])) for ch in chunks)
             for ch, res in zip(chunks, self.readtext_stream(feed, **kw)):
                 for i, r in zip(ch, res):
                     out[i] = format_output(r, output_format, kw.get("paragraph", False), kw.get("detail", 1))
